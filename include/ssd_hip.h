@@ -1,0 +1,115 @@
+/*
+ * ssd_hip.h -- C ABI of the MI355X (gfx950) SSD hot-path library  (libssd_hip.so)
+ *
+ * Drop-in boundary for the data-parallel hot path of AcherStyx/SSD-Object-Detection.
+ * The reference is pure Python (TensorFlow + numpy) and has no FFI; each entry point below
+ * replaces one Python-level seam, cited as <file>:<line> relative to the reference tree.
+ * INTEGRATION.md shows the ctypes stub a reference maintainer would add at each seam.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / C++ types.
+ *   - Unless a parameter says HOST, every pointer is a DEVICE pointer owned by the caller.
+ *     The library allocates nothing, keeps no mutable global state and creates no streams;
+ *     scratch is passed as (ws, ws_bytes) sized by the matching *_workspace_bytes().
+ *   - `stream` (last argument) is a hipStream_t passed as void*; all work is enqueued on it
+ *     and nothing synchronises the host, so every call can be captured into a hipGraph.
+ *   - Return value: SSD_OK (0) or a negative ssd_status.  Kernels never abort.  The Python
+ *     wrapper maps SSD_ERR_ASSERT to AssertionError and SSD_ERR_VALUE to ValueError, the
+ *     exception types the reference raises at the same seams.
+ *   - Layouts: boxes are (cx, cy, w, h); activations NHWC; conv weights [Cout][kh][kw][Cin].
+ */
+#ifndef SSD_HIP_H
+#define SSD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    SSD_OK = 0,
+    SSD_ERR_ASSERT = -1,    /* a reference `assert` would have fired (utils/bbox.py:50-51,95; models/ssd_model.py:347-351,375) */
+    SSD_ERR_VALUE = -2,     /* bad argument (reference: ValueError / TF InvalidArgument)                    */
+    SSD_ERR_WORKSPACE = -3, /* ws_bytes smaller than *_workspace_bytes()                                    */
+    SSD_ERR_LAUNCH = -4,    /* HIP launch failure (hipGetLastError != hipSuccess)                           */
+    SSD_ERR_UNSUPPORTED = -5
+} ssd_status;
+
+typedef enum { SSD_F32 = 0, SSD_BF16 = 1 } ssd_dtype;
+
+int ssd_hip_abi_version(void);
+const char* ssd_status_string(int status);
+
+/* ------------------------------------------------------------------------------------------
+ * Default boxes -- replaces SSDObjectDetectionModel._build_prior_box (models/ssd_model.py:173-194)
+ *   grid_hw    HOST int[2*levels]   (h, w) per level            (reference: loc-head output shapes, :164)
+ *   s_ref      HOST double[levels+1]                            (:176)
+ *   ratios     HOST int[ratio_off[levels]], ratio_off HOST int[levels+1]   (:177, CSR form)
+ *   in_size    input side in pixels (300)                       (:184)
+ *   out        DEVICE double[A*4], A = ssd_priors_count(...)    (cx,cy,w,h), unclipped, reference order
+ * Bit-exact against the reference's float64 array.
+ * ---------------------------------------------------------------------------------------- */
+int ssd_priors_count(const int* grid_hw, int levels, const int* ratio_off);
+int ssd_priors(const int* grid_hw, int levels, const double* s_ref, const int* ratios,
+               const int* ratio_off, double in_size, double* out, void* stream);
+
+/* Geometry of a prior set made by ssd_priors (levels <= SSD_MAX_LEVELS). */
+#define SSD_MAX_LEVELS 8
+typedef struct {
+    int levels;
+    int grid_h[SSD_MAX_LEVELS];
+    int grid_w[SSD_MAX_LEVELS];
+    int per_cell[SSD_MAX_LEVELS]; /* priors per cell = 2 + 2*len(ratios[level]) */
+} ssd_prior_grid;
+
+/* Encoding of an all-zero (unmatched) target row against every prior: the value
+ * apply_anchor_box (utils/bbox.py:94-101) produces for rows match_bbox left at 0, cast to f32 as
+ * the TensorSpec at models/ssd_model.py:222 does.  Image-independent; computed once.
+ *   priors DEVICE double[A*4] -> enc_zero DEVICE float[A*4] */
+int ssd_encode_zero(const double* priors, int A, float* enc_zero, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Batched target assignment -- replaces, for a whole batch, the per-image generator body
+ *   match_bbox(cls, bbox, prior_box, thresh)   utils/bbox.py:44-91   (called models/ssd_model.py:212)
+ *   apply_anchor_box(matched_loc, prior_box)   utils/bbox.py:94-101  (called models/ssd_model.py:213)
+ *   + the float32 cast of the TensorSpec        models/ssd_model.py:222
+ *
+ *   gt_box   float[total_gt*4]  all images' boxes, concatenated (cx,cy,w,h in [0,1], w,h >= 0, finite)
+ *   gt_cls   float[total_gt]    class ids stored as float (as the loaders emit them)
+ *   gt_off   int32[B+1]         image b owns rows gt_off[b] .. gt_off[b+1]-1   (DEVICE)
+ *   total_gt, max_nt            HOST-known sum / max of per-image counts (max_nt <= A else SSD_ERR_ASSERT, :50)
+ *   priors   double[A*4]; enc_zero float[A*4] from ssd_encode_zero
+ *   grid     HOST, may be NULL.  Optional speed hint: the geometry `priors` was generated with
+ *            (ssd_priors).  It only seeds a pruning bound; results are identical with, without
+ *            or with a wrong hint.
+ *   thresh   > 0 else SSD_ERR_ASSERT (:51)
+ *   out_cls  int32[B*A]   (0 where unmatched -- not the background id, as in the reference)
+ *   out_loc  float[B*A*4] encoded offsets (finite "zero-row" values where unmatched, as in the reference)
+ *   out_mask uint8[B*A]   1 = positive
+ *   out_owner int32[B*A] or NULL: the matched gt row of each anchor within its image (-1 = unmatched),
+ *            i.e. index_list of utils/bbox.py:60-79 as a dense map.  The training path passes NULL.
+ * Anchor indices / classes / masks are bit-exact with the reference; out_loc is bit-exact in
+ * the division terms and <= 1 float32 ulp in the log terms (device log vs numpy log).
+ * ---------------------------------------------------------------------------------------- */
+size_t ssd_match_encode_workspace_bytes(int B, int A, int total_gt);
+int ssd_match_encode(const float* gt_box, const float* gt_cls, const int32_t* gt_off, int B,
+                     int total_gt, int max_nt, const double* priors, const float* enc_zero, int A,
+                     const ssd_prior_grid* grid, double thresh, int32_t* out_cls, float* out_loc,
+                     uint8_t* out_mask, int32_t* out_owner, void* ws, size_t ws_bytes, void* stream);
+
+/* apply_anchor_box (utils/bbox.py:94-101) on n paired rows: float32 boxes against float64 priors,
+ * float64 result [n*4] exactly as numpy returns it (division terms bit-exact, log terms <= 1 ulp).
+ * The same shapes are required of both inputs by the reference's assert (:95); the wrapper checks. */
+int ssd_apply_anchor_box(const float* box, const double* priors, int n, double* out, void* stream);
+
+/* Pairwise IoU, the reference's iou_n (utils/bbox.py:28-41) for float32 box_1 rows against
+ * float64 box_2 rows (the dtype mix match_bbox feeds it): out[i] = iou(b1[i], b2[i]), float64,
+ * bit-exact.  Exposed for parity tests and for callers of iou_n. */
+int ssd_iou_n(const float* b1, const double* b2, int n, double* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSD_HIP_H */

@@ -1,0 +1,69 @@
+"""ctypes binding of libssd_hip.so (include/ssd_hip.h).  Fails loudly when the library is absent."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libssd_hip.so")
+
+SSD_OK, SSD_ERR_ASSERT, SSD_ERR_VALUE, SSD_ERR_WORKSPACE, SSD_ERR_LAUNCH, SSD_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+SSD_MAX_LEVELS = 8
+
+_c_int_p = ctypes.POINTER(ctypes.c_int)
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+VP = ctypes.c_void_p
+
+
+class PriorGrid(ctypes.Structure):
+    _fields_ = [("levels", ctypes.c_int),
+                ("grid_h", ctypes.c_int * SSD_MAX_LEVELS),
+                ("grid_w", ctypes.c_int * SSD_MAX_LEVELS),
+                ("per_cell", ctypes.c_int * SSD_MAX_LEVELS)]
+
+
+_SIGNATURES = {
+    "ssd_hip_abi_version": (ctypes.c_int, []),
+    "ssd_status_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "ssd_priors_count": (ctypes.c_int, [_c_int_p, ctypes.c_int, _c_int_p]),
+    "ssd_priors": (ctypes.c_int, [_c_int_p, ctypes.c_int, _c_double_p, _c_int_p, _c_int_p, ctypes.c_double, VP, VP]),
+    "ssd_encode_zero": (ctypes.c_int, [VP, ctypes.c_int, VP, VP]),
+    "ssd_match_encode_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "ssd_match_encode": (ctypes.c_int, [VP, VP, VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, VP, VP, ctypes.c_int,
+                                        ctypes.POINTER(PriorGrid), ctypes.c_double, VP, VP, VP, VP, VP, ctypes.c_size_t, VP]),
+    "ssd_apply_anchor_box": (ctypes.c_int, [VP, VP, ctypes.c_int, VP, VP]),
+    "ssd_iou_n": (ctypes.c_int, [VP, VP, ctypes.c_int, VP, VP]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the C-ABI library.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libssd_hip.so is missing (%s): build it with `python ssd-object-detection_amd/build.py` "
+                "or __graft_entry__.build(); there is no CPU fallback." % LIB_PATH)
+        try:
+            import torch  # noqa: F401  -- load torch's HIP runtime first so both share one libamdhip64
+        except ImportError:
+            pass
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status):
+    """Map a C-ABI status to the exception type the reference raises at the same seam."""
+    if status == SSD_OK:
+        return
+    msg = lib().ssd_status_string(status).decode()
+    if status == SSD_ERR_ASSERT:
+        raise AssertionError(msg)
+    if status in (SSD_ERR_VALUE, SSD_ERR_UNSUPPORTED):
+        raise ValueError(msg)
+    raise RuntimeError("ssd_hip: %s (status %d)" % (msg, status))

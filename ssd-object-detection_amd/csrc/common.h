@@ -1,0 +1,16 @@
+// Shared helpers for the gfx950 SSD hot-path library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ssd_hip.h"
+
+#define SSD_ABI_VERSION 1
+
+static inline int ssd_launch_status() {
+    return hipGetLastError() == hipSuccess ? SSD_OK : SSD_ERR_LAUNCH;
+}
+
+static inline size_t ssd_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// 64-lane wavefront helpers (gfx950: wave64 only)
+#define SSD_WAVE 64

@@ -1,0 +1,581 @@
+// Batched anchor matching + box encoding for gfx950 (MI355X).
+//
+// Replaces utils/bbox.py:44-101 of the reference (match_bbox + apply_anchor_box, driven per image
+// from models/ssd_model.py:212-213) for a whole batch in two launches:
+//
+//   k_match_pairs   grid (chunks, B): one thread per prior column, all of the image's gt rows.
+//                   Streams priors in (f64, L2-resident), writes cls/loc/mask out (the HBM
+//                   traffic), computes the mixed f32/f64 IoU arithmetic of iou_n
+//                   (utils/bbox.py:28-41) bit-exactly but WITHOUT a division for almost every
+//                   pair: a pair is only divided out when inter >= bound*union, where bound is
+//                   a proven lower bound of what could still matter (column: current column
+//                   best, starting at thresh; row: an exactly evaluated seed of the row
+//                   maximum).  Emits phase-2 assignments (column max > thresh -> lowest row
+//                   attaining it) and, per (row, chunk), the best column candidate.
+//   k_match_phase1  grid (B): reduces the row candidates, runs the sequential phase 1
+//                   (utils/bbox.py:62-68).  If all row-best columns are distinct the n_t rounds
+//                   collapse to "every row takes its best column"; otherwise the literal
+//                   round-by-round elimination is run with exact re-scans.  Patches the <= n_t
+//                   phase-1 columns in the outputs.
+//
+// Compile with -ffp-contract=off: results must match numpy's unfused IEEE arithmetic bit for bit.
+#include "common.h"
+#include <limits.h>
+
+namespace {
+
+constexpr int WG = 256;
+constexpr int NWAVE = WG / SSD_WAVE;
+constexpr int RT = 128;                      // gt rows staged in LDS per tile
+#define SSD_MARGIN (1.0 - 0x1p-50)           // filter slack: see DESIGN.md "division-free pruning"
+
+struct Corner {                              // (x_lo, y_lo, x_hi, y_hi, area) of one box, as f64
+    double lx, ly, hx, hy, a;
+};
+
+// gt side of iou_n: corners and area evaluated in float32, then widened (numpy promotion).
+__device__ __forceinline__ Corner gt_corner(float4 g) {
+    const float hw = g.z / 2.0f, hh = g.w / 2.0f;
+    Corner c;
+    c.lx = (double)(g.x - hw);
+    c.ly = (double)(g.y - hh);
+    c.hx = (double)(g.x + hw);
+    c.hy = (double)(g.y + hh);
+    c.a = (double)(g.z * g.w);
+    return c;
+}
+
+// prior side of iou_n: float64 throughout.
+__device__ __forceinline__ Corner prior_corner(double cx, double cy, double w, double h) {
+    Corner c;
+    c.lx = cx - w / 2.0;
+    c.ly = cy - h / 2.0;
+    c.hx = cx + w / 2.0;
+    c.hy = cy + h / 2.0;
+    c.a = w * h;
+    return c;
+}
+
+// intersection (sides clamped at 1e-10) and union (+1e-10) exactly as utils/bbox.py:34-41.
+__device__ __forceinline__ void inter_union(const Corner& g, const Corner& p, double& inter, double& uni) {
+    const double x_lo = fmax(g.lx, p.lx);
+    const double y_lo = fmax(g.ly, p.ly);
+    const double x_hi = fmin(g.hx, p.hx);
+    const double y_hi = fmin(g.hy, p.hy);
+    inter = fmax(1e-10, x_hi - x_lo) * fmax(1e-10, y_hi - y_lo);
+    uni = g.a + p.a - inter + 1e-10;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// (q, c) ordering used everywhere for "first maximum in row-major order": larger q wins, ties go
+// to the smaller index.
+__device__ __forceinline__ bool better(double q, int c, double bq, int bc) {
+    return q > bq || (q == bq && c < bc);
+}
+
+// apply_anchor_box for one matched row (utils/bbox.py:98-99), cast to f32 (ssd_model.py:222).
+__device__ __forceinline__ float4 encode_row(float4 g, double pcx, double pcy, double pw, double ph) {
+    float4 o;
+    o.x = (float)(((double)g.x - pcx) / pw);
+    o.y = (float)(((double)g.y - pcy) / ph);
+    o.z = (float)log((double)fmaxf(g.z, 1e-5f) / fmax(pw, 1e-5));
+    o.w = (float)log((double)fmaxf(g.w, 1e-5f) / fmax(ph, 1e-5));
+    return o;
+}
+
+struct GridHint {
+    int levels;
+    int gh[SSD_MAX_LEVELS], gw[SSD_MAX_LEVELS], k[SSD_MAX_LEVELS];
+    int col_off[SSD_MAX_LEVELS + 1];        // first column of each level
+    int cand_off[SSD_MAX_LEVELS + 1];       // prefix sum of k
+};
+
+// ------------------------------------------------------------------------------------------------
+template <int CPT>
+__global__ __launch_bounds__(WG) void k_match_pairs(
+    const float4* __restrict__ gt_box, const float* __restrict__ gt_cls, const int* __restrict__ gt_off,
+    const double* __restrict__ priors, const float4* __restrict__ enc_zero, int A, double thresh,
+    GridHint hint, int* __restrict__ out_cls, float4* __restrict__ out_loc, uint8_t* __restrict__ out_mask,
+    int* __restrict__ out_owner, double* __restrict__ part_q, int* __restrict__ part_c, int nchunk) {
+    __shared__ Corner s_row[RT];
+    __shared__ double s_lbm[RT];
+    __shared__ unsigned long long s_seed[RT];
+    __shared__ double s_wq[NWAVE][RT];
+    __shared__ int s_wc[NWAVE][RT];
+
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g0 = gt_off[b];
+    const int nt = gt_off[b + 1] - g0;
+    const int cbase = chunk * (WG * CPT);
+
+    Corner pc[CPT];
+    double p4[CPT][4];
+    bool valid[CPT];
+    double cbq[CPT], cbm[CPT];
+    int cbr[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int c = cbase + j * WG + tid;
+        valid[j] = c < A;
+        const int cc = valid[j] ? c : A - 1;
+        const double2 lo = *reinterpret_cast<const double2*>(priors + 4 * (size_t)cc);
+        const double2 hi = *reinterpret_cast<const double2*>(priors + 4 * (size_t)cc + 2);
+        p4[j][0] = lo.x; p4[j][1] = lo.y; p4[j][2] = hi.x; p4[j][3] = hi.y;
+        pc[j] = prior_corner(lo.x, lo.y, hi.x, hi.y);
+        cbq[j] = thresh;                       // phase 2 needs max > thresh (utils/bbox.py:73)
+        cbm[j] = thresh * SSD_MARGIN;
+        cbr[j] = -1;
+    }
+
+    for (int t0 = 0; t0 < nt; t0 += RT) {
+        const int nr = min(RT, nt - t0);
+        __syncthreads();
+        if (tid < nr) {
+            const float4 g = gt_box[g0 + t0 + tid];
+            s_row[tid] = gt_corner(g);
+            s_seed[tid] = 0ull;
+#pragma unroll
+            for (int w = 0; w < NWAVE; ++w) { s_wq[w][tid] = 0.0; s_wc[w][tid] = INT_MAX; }
+        }
+        __syncthreads();
+        // exact seeds of the row maxima from the cells under the gt centre (speed hint only)
+        if (hint.levels > 0) {
+            const int ncand = hint.cand_off[hint.levels];
+            for (int i = tid; i < nr * ncand; i += WG) {
+                const int r = i / ncand, k = i - r * ncand;
+                int l = 0;
+                while (l + 1 < hint.levels && k >= hint.cand_off[l + 1]) ++l;
+                const float4 g = gt_box[g0 + t0 + r];
+                int x = (int)floorf(g.x * (float)hint.gw[l]);
+                int y = (int)floorf(g.y * (float)hint.gh[l]);
+                x = min(max(x, 0), hint.gw[l] - 1);
+                y = min(max(y, 0), hint.gh[l] - 1);
+                int c = hint.col_off[l] + (y * hint.gw[l] + x) * hint.k[l] + (k - hint.cand_off[l]);
+                c = min(max(c, 0), A - 1);
+                const double2 lo = *reinterpret_cast<const double2*>(priors + 4 * (size_t)c);
+                const double2 hi = *reinterpret_cast<const double2*>(priors + 4 * (size_t)c + 2);
+                double inter, uni;
+                inter_union(s_row[r], prior_corner(lo.x, lo.y, hi.x, hi.y), inter, uni);
+                const double q = inter / uni;
+                if (q > 0.0) atomicMax(&s_seed[r], (unsigned long long)__double_as_longlong(q));
+            }
+        }
+        __syncthreads();
+        if (tid < nr) s_lbm[tid] = __longlong_as_double((long long)s_seed[tid]) * SSD_MARGIN;
+        __syncthreads();
+
+        for (int r = 0; r < nr; ++r) {
+            const Corner g = s_row[r];
+            const double lbm = s_lbm[r];
+            double wbq = 0.0;                  // best row candidate of this wave (uniform)
+            int wbc = INT_MAX;
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                double inter, uni;
+                inter_union(g, pc[j], inter, uni);
+                const double bound = fmin(cbm[j], lbm);
+                const bool pass = valid[j] && (inter >= bound * uni);
+                if (__ballot(pass)) {          // rare: some lane needs the exact quotient
+                    double q = 0.0;
+                    bool rowcand = false;
+                    if (pass) {
+                        q = inter / uni;
+                        if (q > cbq[j]) { cbq[j] = q; cbr[j] = t0 + r; cbm[j] = q * SSD_MARGIN; }
+                        rowcand = q >= lbm;
+                    }
+                    unsigned long long m = __ballot(rowcand);
+                    while (m) {
+                        const int l = __ffsll((long long)m) - 1;
+                        const double ql = readlane_f64(q, l);
+                        const int cl = cbase + j * WG + (wave << 6) + l;
+                        if (better(ql, cl, wbq, wbc)) { wbq = ql; wbc = cl; }
+                        m &= m - 1;
+                    }
+                }
+            }
+            if (lane == 0 && wbc != INT_MAX) { s_wq[wave][r] = wbq; s_wc[wave][r] = wbc; }
+        }
+        __syncthreads();
+        if (tid < nr) {
+            double bq = 0.0;
+            int bc = INT_MAX;
+#pragma unroll
+            for (int w = 0; w < NWAVE; ++w)
+                if (s_wc[w][tid] != INT_MAX && better(s_wq[w][tid], s_wc[w][tid], bq, bc)) {
+                    bq = s_wq[w][tid];
+                    bc = s_wc[w][tid];
+                }
+            const size_t slot = (size_t)(g0 + t0 + tid) * nchunk + chunk;
+            part_q[slot] = bq;
+            part_c[slot] = bc;
+        }
+    }
+
+    // phase-2 outputs for this thread's columns (phase-1 columns are patched by k_match_phase1)
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        if (!valid[j]) continue;
+        const int c = cbase + j * WG + tid;
+        const size_t o = (size_t)b * A + c;
+        if (out_owner) out_owner[o] = cbr[j];
+        if (cbr[j] >= 0) {
+            const float4 g = gt_box[g0 + cbr[j]];
+            out_cls[o] = (int)gt_cls[g0 + cbr[j]];
+            out_mask[o] = 1;
+            out_loc[o] = encode_row(g, p4[j][0], p4[j][1], p4[j][2], p4[j][3]);
+        } else {
+            out_cls[o] = 0;
+            out_mask[o] = 0;
+            out_loc[o] = enc_zero[c];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Workgroup-wide argmax of (q, idx) with the `better` ordering. Result broadcast to all threads.
+__device__ __forceinline__ void wg_argmax(double& q, int& c, double* s_q, int* s_c) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double oq = __shfl_xor(q, off);
+        const int oc = __shfl_xor(c, off);
+        if (better(oq, oc, q, c)) { q = oq; c = oc; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) { s_q[wave] = q; s_c[wave] = c; }
+    __syncthreads();
+    q = s_q[0]; c = s_c[0];
+#pragma unroll
+    for (int w = 1; w < NWAVE; ++w)
+        if (better(s_q[w], s_c[w], q, c)) { q = s_q[w]; c = s_c[w]; }
+}
+
+// Exact maximum of one gt row over all columns whose bit in `taken` is clear; first maximum wins.
+__device__ __forceinline__ void row_scan(const Corner& g, const double* __restrict__ priors, int A,
+                                         const unsigned* taken, double& q_out, int& c_out,
+                                         double* s_q, int* s_c) {
+    double bq = -1.0, bqm = -1.0;
+    int bc = INT_MAX;
+    for (int c = threadIdx.x; c < A; c += WG) {
+        if (taken[c >> 5] & (1u << (c & 31))) continue;
+        const double2 lo = *reinterpret_cast<const double2*>(priors + 4 * (size_t)c);
+        const double2 hi = *reinterpret_cast<const double2*>(priors + 4 * (size_t)c + 2);
+        double inter, uni;
+        inter_union(g, prior_corner(lo.x, lo.y, hi.x, hi.y), inter, uni);
+        if (inter >= bqm * uni) {
+            const double q = inter / uni;
+            if (q > bq) { bq = q; bc = c; bqm = q * SSD_MARGIN; }
+        }
+    }
+    wg_argmax(bq, bc, s_q, s_c);
+    q_out = bq;
+    c_out = bc;
+}
+
+__global__ __launch_bounds__(WG) void k_match_phase1(
+    const float4* __restrict__ gt_box, const float* __restrict__ gt_cls, const int* __restrict__ gt_off,
+    const double* __restrict__ priors, int A, int nchunk, const double* __restrict__ part_q,
+    const int* __restrict__ part_c, double* row_q, int* row_c, int* row_state,
+    int* __restrict__ out_cls, float4* __restrict__ out_loc, uint8_t* __restrict__ out_mask,
+    int* __restrict__ out_owner) {
+    extern __shared__ unsigned s_taken[];      // A-bit map of phase-1 columns
+    __shared__ double s_q[NWAVE];
+    __shared__ int s_c[NWAVE];
+    __shared__ int s_flag;
+
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int g0 = gt_off[b];
+    const int nt = gt_off[b + 1] - g0;
+    const int nwords = (A + 31) >> 5;
+    for (int i = tid; i < nwords; i += WG) s_taken[i] = 0u;
+    if (tid == 0) s_flag = 0;
+    __syncthreads();
+
+    // reduce the per-chunk row candidates
+    for (int r = tid; r < nt; r += WG) {
+        double bq = 0.0;
+        int bc = INT_MAX;
+        const size_t base = (size_t)(g0 + r) * nchunk;
+        for (int k = 0; k < nchunk; ++k) {
+            const int c = part_c[base + k];
+            if (c != INT_MAX && better(part_q[base + k], c, bq, bc)) { bq = part_q[base + k]; bc = c; }
+        }
+        row_q[g0 + r] = bq;
+        row_c[g0 + r] = bc;
+        row_state[g0 + r] = 1;                 // 1 = still free
+        if (bc == INT_MAX) atomicOr(&s_flag, 2);
+    }
+    __syncthreads();
+    if (s_flag & 2) {                          // a row without candidate (never for valid boxes): exact scan
+        for (int r = 0; r < nt; ++r) {
+            if (row_c[g0 + r] != INT_MAX) continue;
+            double q; int c;
+            row_scan(gt_corner(gt_box[g0 + r]), priors, A, s_taken, q, c, s_q, s_c);
+            if (tid == 0) { row_q[g0 + r] = q; row_c[g0 + r] = c; }
+            __syncthreads();
+        }
+    }
+    // are the row-best columns pairwise distinct?
+    for (int r = tid; r < nt; r += WG) {
+        const int c = row_c[g0 + r];
+        const unsigned bit = 1u << (c & 31);
+        if (atomicOr(&s_taken[c >> 5], bit) & bit) atomicOr(&s_flag, 1);
+    }
+    __syncthreads();
+    if (s_flag & 1) {
+        // literal phase 1 (utils/bbox.py:62-68): n_t rounds of global argmax with row+column
+        // elimination; rows whose best column was just taken are re-scanned exactly.
+        for (int i = tid; i < nwords; i += WG) s_taken[i] = 0u;
+        __syncthreads();
+        for (int round = 0; round < nt; ++round) {
+            double bq = -1.0;
+            int br = INT_MAX;
+            for (int r = tid; r < nt; r += WG)
+                if (row_state[g0 + r] == 1 && better(row_q[g0 + r], r, bq, br)) { bq = row_q[g0 + r]; br = r; }
+            wg_argmax(bq, br, s_q, s_c);
+            const int cstar = row_c[g0 + br];
+            __syncthreads();
+            if (tid == 0) {
+                row_state[g0 + br] = 0;
+                s_taken[cstar >> 5] |= 1u << (cstar & 31);
+            }
+            __syncthreads();
+            for (int r = 0; r < nt; ++r) {     // uniform loop; conflicts are rare
+                if (row_state[g0 + r] != 1 || row_c[g0 + r] != cstar) continue;
+                double q; int c;
+                row_scan(gt_corner(gt_box[g0 + r]), priors, A, s_taken, q, c, s_q, s_c);
+                __syncthreads();
+                if (tid == 0) { row_q[g0 + r] = q; row_c[g0 + r] = c; }
+                __syncthreads();
+            }
+        }
+    }
+    // patch the phase-1 columns (utils/bbox.py:84-90 scatter + apply_anchor_box)
+    for (int r = tid; r < nt; r += WG) {
+        const int c = row_c[g0 + r];
+        const size_t o = (size_t)b * A + c;
+        const float4 g = gt_box[g0 + r];
+        const double2 lo = *reinterpret_cast<const double2*>(priors + 4 * (size_t)c);
+        const double2 hi = *reinterpret_cast<const double2*>(priors + 4 * (size_t)c + 2);
+        out_cls[o] = (int)gt_cls[g0 + r];
+        out_mask[o] = 1;
+        out_loc[o] = encode_row(g, lo.x, lo.y, hi.x, hi.y);
+        if (out_owner) out_owner[o] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void k_iou_n(const float4* __restrict__ b1, const double* __restrict__ b2, int n,
+                        double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double2 lo = *reinterpret_cast<const double2*>(b2 + 4 * (size_t)i);
+    const double2 hi = *reinterpret_cast<const double2*>(b2 + 4 * (size_t)i + 2);
+    double inter, uni;
+    inter_union(gt_corner(b1[i]), prior_corner(lo.x, lo.y, hi.x, hi.y), inter, uni);
+    out[i] = inter / uni;
+}
+
+// apply_anchor_box (utils/bbox.py:94-101) on n paired rows, float64 result as numpy produces.
+__global__ void k_apply_anchor_box(const float4* __restrict__ box, const double* __restrict__ priors, int n,
+                                   double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 g = box[i];
+    const double2 lo = *reinterpret_cast<const double2*>(priors + 4 * (size_t)i);
+    const double2 hi = *reinterpret_cast<const double2*>(priors + 4 * (size_t)i + 2);
+    double* o = out + 4 * (size_t)i;
+    o[0] = ((double)g.x - lo.x) / hi.x;
+    o[1] = ((double)g.y - lo.y) / hi.y;
+    o[2] = log((double)fmaxf(g.z, 1e-5f) / fmax(hi.x, 1e-5));
+    o[3] = log((double)fmaxf(g.w, 1e-5f) / fmax(hi.y, 1e-5));
+}
+
+__global__ void k_encode_zero(const double* __restrict__ priors, int A, float4* __restrict__ enc_zero) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= A) return;
+    const double2 lo = *reinterpret_cast<const double2*>(priors + 4 * (size_t)c);
+    const double2 hi = *reinterpret_cast<const double2*>(priors + 4 * (size_t)c + 2);
+    enc_zero[c] = encode_row(make_float4(0.f, 0.f, 0.f, 0.f), lo.x, lo.y, hi.x, hi.y);
+}
+
+struct PriorLevels {
+    int levels;
+    int gh[SSD_MAX_LEVELS], gw[SSD_MAX_LEVELS], k[SSD_MAX_LEVELS], col_off[SSD_MAX_LEVELS + 1];
+    double s_k[SSD_MAX_LEVELS], s_prime[SSD_MAX_LEVELS];
+    int ratio_off[SSD_MAX_LEVELS + 1];
+    double ratio_sqrt[4 * SSD_MAX_LEVELS];   // host-computed sqrt(ratio) (correctly rounded, as math.sqrt)
+};
+
+// models/ssd_model.py:173-194.  s_k and s' are computed on the host with the same IEEE
+// operations (division, multiply, correctly rounded sqrt); per-prior terms here.
+__global__ void k_priors(PriorLevels L, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.col_off[L.levels]) return;
+    int l = 0;
+    while (l + 1 < L.levels && i >= L.col_off[l + 1]) ++l;
+    const int rel = i - L.col_off[l];
+    const int cell = rel / L.k[l], j = rel - cell * L.k[l];
+    const int y = cell / L.gw[l], x = cell - y * L.gw[l];
+    const double cx = ((double)x + 0.5) / (double)L.gw[l];
+    const double cy = ((double)y + 0.5) / (double)L.gh[l];
+    double w, h;
+    if (j == 0) { w = h = L.s_k[l]; }
+    else if (j == 1) { w = h = L.s_prime[l]; }
+    else {
+        const int ri = (j - 2) >> 1;
+        const double q = L.ratio_sqrt[L.ratio_off[l] + ri];
+        if (((j - 2) & 1) == 0) { w = L.s_k[l] * q; h = L.s_k[l] / q; }
+        else { w = L.s_k[l] / q; h = L.s_k[l] * q; }
+    }
+    double* o = out + 4 * (size_t)i;
+    o[0] = cx; o[1] = cy; o[2] = w; o[3] = h;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+int ssd_hip_abi_version(void) { return SSD_ABI_VERSION; }
+
+const char* ssd_status_string(int status) {
+    switch (status) {
+        case SSD_OK: return "ok";
+        case SSD_ERR_ASSERT: return "assertion of the reference violated";
+        case SSD_ERR_VALUE: return "invalid argument";
+        case SSD_ERR_WORKSPACE: return "workspace too small";
+        case SSD_ERR_LAUNCH: return "HIP launch failed";
+        case SSD_ERR_UNSUPPORTED: return "unsupported configuration";
+        default: return "unknown status";
+    }
+}
+
+int ssd_priors_count(const int* grid_hw, int levels, const int* ratio_off) {
+    if (!grid_hw || !ratio_off || levels <= 0 || levels > SSD_MAX_LEVELS) return SSD_ERR_VALUE;
+    long long n = 0;
+    for (int l = 0; l < levels; ++l)
+        n += (long long)grid_hw[2 * l] * grid_hw[2 * l + 1] * (2 + 2 * (ratio_off[l + 1] - ratio_off[l]));
+    return n > INT_MAX ? SSD_ERR_VALUE : (int)n;
+}
+
+int ssd_priors(const int* grid_hw, int levels, const double* s_ref, const int* ratios, const int* ratio_off,
+               double in_size, double* out, void* stream) {
+    const int A = ssd_priors_count(grid_hw, levels, ratio_off);
+    if (A <= 0 || !s_ref || !ratios || !out || !(in_size > 0.0)) return SSD_ERR_VALUE;
+    if (ratio_off[levels] > 4 * SSD_MAX_LEVELS) return SSD_ERR_UNSUPPORTED;
+    PriorLevels L;
+    L.levels = levels;
+    L.col_off[0] = 0;
+    for (int l = 0; l < levels; ++l) {
+        L.gh[l] = grid_hw[2 * l];
+        L.gw[l] = grid_hw[2 * l + 1];
+        L.k[l] = 2 + 2 * (ratio_off[l + 1] - ratio_off[l]);
+        L.col_off[l + 1] = L.col_off[l] + L.gh[l] * L.gw[l] * L.k[l];
+        const double s_k = s_ref[l] / in_size;                       // :184
+        L.s_k[l] = s_k;
+        L.s_prime[l] = __builtin_sqrt(s_k * (s_ref[l + 1] / in_size));   // :187
+        L.ratio_off[l] = ratio_off[l];
+    }
+    L.ratio_off[levels] = ratio_off[levels];
+    for (int i = 0; i < ratio_off[levels]; ++i) L.ratio_sqrt[i] = __builtin_sqrt((double)ratios[i]);   // :191
+    hipLaunchKernelGGL(k_priors, dim3((A + 255) / 256), dim3(256), 0, (hipStream_t)stream, L, out);
+    return ssd_launch_status();
+}
+
+int ssd_encode_zero(const double* priors, int A, float* enc_zero, void* stream) {
+    if (!priors || !enc_zero || A <= 0) return SSD_ERR_VALUE;
+    hipLaunchKernelGGL(k_encode_zero, dim3((A + 255) / 256), dim3(256), 0, (hipStream_t)stream, priors, A,
+                       reinterpret_cast<float4*>(enc_zero));
+    return ssd_launch_status();
+}
+
+int ssd_apply_anchor_box(const float* box, const double* priors, int n, double* out, void* stream) {
+    if (n < 0 || (n > 0 && (!box || !priors || !out))) return SSD_ERR_VALUE;
+    if (n == 0) return SSD_OK;
+    hipLaunchKernelGGL(k_apply_anchor_box, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(box), priors, n, out);
+    return ssd_launch_status();
+}
+
+int ssd_iou_n(const float* b1, const double* b2, int n, double* out, void* stream) {
+    if (n < 0 || (n > 0 && (!b1 || !b2 || !out))) return SSD_ERR_VALUE;
+    if (n == 0) return SSD_OK;
+    hipLaunchKernelGGL(k_iou_n, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(b1), b2, n, out);
+    return ssd_launch_status();
+}
+
+static constexpr int kMatchCPT = 1;
+static inline int match_nchunk(int A) { return (A + WG * kMatchCPT - 1) / (WG * kMatchCPT); }
+
+size_t ssd_match_encode_workspace_bytes(int B, int A, int total_gt) {
+    (void)B;
+    if (A <= 0 || total_gt < 0) return 0;
+    const size_t n = (size_t)(total_gt > 0 ? total_gt : 1);
+    const size_t nchunk = (size_t)match_nchunk(A);
+    size_t bytes = 0;
+    bytes += ssd_align_up(n * nchunk * sizeof(double), 256);   // part_q
+    bytes += ssd_align_up(n * nchunk * sizeof(int), 256);      // part_c
+    bytes += ssd_align_up(n * sizeof(double), 256);            // row_q
+    bytes += 2 * ssd_align_up(n * sizeof(int), 256);           // row_c, row_state
+    return bytes;
+}
+
+int ssd_match_encode(const float* gt_box, const float* gt_cls, const int32_t* gt_off, int B, int total_gt,
+                     int max_nt, const double* priors, const float* enc_zero, int A, const ssd_prior_grid* grid,
+                     double thresh, int32_t* out_cls, float* out_loc, uint8_t* out_mask, int32_t* out_owner,
+                     void* ws, size_t ws_bytes, void* stream) {
+    if (B < 0 || A <= 0 || total_gt < 0 || max_nt < 0) return SSD_ERR_VALUE;
+    if (max_nt > A) return SSD_ERR_ASSERT;                     // utils/bbox.py:50
+    if (!(thresh > 0.0)) return SSD_ERR_ASSERT;                // utils/bbox.py:51
+    if (B == 0) return SSD_OK;
+    if (!gt_off || !priors || !enc_zero || !out_cls || !out_loc || !out_mask) return SSD_ERR_VALUE;
+    if (total_gt > 0 && (!gt_box || !gt_cls)) return SSD_ERR_VALUE;
+    if (ws_bytes < ssd_match_encode_workspace_bytes(B, A, total_gt) || !ws) return SSD_ERR_WORKSPACE;
+    const size_t lds_bitmap = (size_t)((A + 31) / 32) * sizeof(unsigned);
+    if (lds_bitmap > 96 * 1024) return SSD_ERR_UNSUPPORTED;
+
+    GridHint hint;
+    hint.levels = 0;
+    if (grid && grid->levels > 0 && grid->levels <= SSD_MAX_LEVELS) {
+        hint.levels = grid->levels;
+        hint.col_off[0] = hint.cand_off[0] = 0;
+        for (int l = 0; l < grid->levels; ++l) {
+            hint.gh[l] = grid->grid_h[l] > 0 ? grid->grid_h[l] : 1;
+            hint.gw[l] = grid->grid_w[l] > 0 ? grid->grid_w[l] : 1;
+            hint.k[l] = grid->per_cell[l] > 0 ? grid->per_cell[l] : 1;
+            hint.col_off[l + 1] = hint.col_off[l] + hint.gh[l] * hint.gw[l] * hint.k[l];
+            hint.cand_off[l + 1] = hint.cand_off[l] + hint.k[l];
+        }
+    }
+
+    const int nchunk = match_nchunk(A);
+    const size_t n = (size_t)(total_gt > 0 ? total_gt : 1);
+    char* p = static_cast<char*>(ws);
+    double* part_q = reinterpret_cast<double*>(p); p += ssd_align_up(n * nchunk * sizeof(double), 256);
+    int* part_c = reinterpret_cast<int*>(p);       p += ssd_align_up(n * nchunk * sizeof(int), 256);
+    double* row_q = reinterpret_cast<double*>(p);  p += ssd_align_up(n * sizeof(double), 256);
+    int* row_c = reinterpret_cast<int*>(p);        p += ssd_align_up(n * sizeof(int), 256);
+    int* row_state = reinterpret_cast<int*>(p);
+
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_match_pairs<kMatchCPT>, dim3(nchunk, B), dim3(WG), 0, s,
+                       reinterpret_cast<const float4*>(gt_box), gt_cls, gt_off, priors,
+                       reinterpret_cast<const float4*>(enc_zero), A, thresh, hint, out_cls,
+                       reinterpret_cast<float4*>(out_loc), out_mask, out_owner, part_q, part_c, nchunk);
+    if (hipGetLastError() != hipSuccess) return SSD_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_match_phase1, dim3(B), dim3(WG), lds_bitmap, s,
+                       reinterpret_cast<const float4*>(gt_box), gt_cls, gt_off, priors, A, nchunk, part_q,
+                       part_c, row_q, row_c, row_state, out_cls, reinterpret_cast<float4*>(out_loc), out_mask,
+                       out_owner);
+    return ssd_launch_status();
+}
+
+}  // extern "C"

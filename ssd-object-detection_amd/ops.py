@@ -1,0 +1,156 @@
+"""Device-tensor wrappers over the C ABI (include/ssd_hip.h).  torch supplies device memory and the
+current HIP stream only; every computation runs in libssd_hip.so."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+# SSD300 geometry of the reference (models/ssd_model.py:153,164,176-177)
+SSD300_GRIDS = ((38, 38), (19, 19), (10, 10), (5, 5), (3, 3), (1, 1))
+SSD300_S_REF = (21, 45, 99, 153, 207, 261, 315)
+SSD300_RATIOS = ((2,), (2, 3), (2, 3), (2, 3), (2,), (2,))
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, dtype):
+    assert t.is_cuda and t.dtype == dtype and t.is_contiguous(), (t.device, t.dtype, t.is_contiguous())
+    return t
+
+
+class PriorSet:
+    """Default boxes on the device + everything derived from them once (unmatched-row encodings,
+    the geometry hint for the matcher)."""
+
+    def __init__(self, priors, enc_zero, grid=None):
+        self.priors = priors            # f64 [A,4] device
+        self.enc_zero = enc_zero        # f32 [A,4] device
+        self.grid = grid                # _lib.PriorGrid or None
+        self.A = priors.shape[0]
+
+
+def make_grid(grids, ratios):
+    g = _lib.PriorGrid()
+    g.levels = len(grids)
+    for i, ((h, w), r) in enumerate(zip(grids, ratios)):
+        g.grid_h[i], g.grid_w[i], g.per_cell[i] = h, w, 2 + 2 * len(r)
+    return g
+
+
+def build_priors(grids=SSD300_GRIDS, s_ref=SSD300_S_REF, ratios=SSD300_RATIOS, in_size=300, device="cuda"):
+    """ssd_priors + ssd_encode_zero (replaces _build_prior_box, models/ssd_model.py:173-194)."""
+    L = _lib.lib()
+    levels = len(grids)
+    hw = (ctypes.c_int * (2 * levels))(*[v for g in grids for v in g])
+    sref = (ctypes.c_double * (levels + 1))(*[float(s) for s in s_ref])
+    flat = [r for rr in ratios for r in rr]
+    rat = (ctypes.c_int * max(len(flat), 1))(*flat)
+    off = [0]
+    for rr in ratios:
+        off.append(off[-1] + len(rr))
+    roff = (ctypes.c_int * (levels + 1))(*off)
+    A = L.ssd_priors_count(hw, levels, roff)
+    if A <= 0:
+        _lib.check(A if A < 0 else _lib.SSD_ERR_VALUE)
+    pri = torch.empty((A, 4), dtype=torch.float64, device=device)
+    _lib.check(L.ssd_priors(hw, levels, sref, rat, roff, float(in_size), _ptr(pri), _stream()))
+    return prior_set_from(pri, make_grid(grids, ratios))
+
+
+def prior_set_from(priors, grid=None):
+    """Wrap an existing device f64 [A,4] prior array (any geometry)."""
+    L = _lib.lib()
+    priors = _dev(priors, torch.float64)
+    A = priors.shape[0]
+    enc0 = torch.empty((A, 4), dtype=torch.float32, device=priors.device)
+    _lib.check(L.ssd_encode_zero(_ptr(priors), A, _ptr(enc0), _stream()))
+    return PriorSet(priors, enc0, grid)
+
+
+class MatchWorkspace:
+    """Caller-owned scratch for ssd_match_encode, grown on demand."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=device)
+        return self.buf
+
+
+_default_ws = MatchWorkspace()
+
+
+def match_encode(gt_box, gt_cls, gt_off, total_gt, max_nt, pset, thresh=0.5, out=None, ws=None, owner=None):
+    """Batched match_bbox + apply_anchor_box (utils/bbox.py:44-101) on the device.
+
+    gt_box f32[total_gt,4], gt_cls f32[total_gt], gt_off i32[B+1] device tensors; total_gt / max_nt are
+    host ints.  `owner` (optional i32[B,A]) receives the matched gt row per anchor (-1 = none).
+    Returns (cls i32[B,A], loc f32[B,A,4], mask u8[B,A])."""
+    L = _lib.lib()
+    B = gt_off.numel() - 1
+    A = pset.A
+    dev = pset.priors.device
+    _dev(gt_off, torch.int32)
+    if total_gt > 0:
+        _dev(gt_box, torch.float32)
+        _dev(gt_cls, torch.float32)
+    if out is None:
+        out = (torch.empty((B, A), dtype=torch.int32, device=dev),
+               torch.empty((B, A, 4), dtype=torch.float32, device=dev),
+               torch.empty((B, A), dtype=torch.uint8, device=dev))
+    o_cls, o_loc, o_mask = out
+    nbytes = L.ssd_match_encode_workspace_bytes(B, A, total_gt)
+    wbuf = (ws or _default_ws).get(nbytes, dev)
+    grid = ctypes.byref(pset.grid) if pset.grid is not None else None
+    _lib.check(L.ssd_match_encode(_ptr(gt_box), _ptr(gt_cls), _ptr(gt_off), B, int(total_gt), int(max_nt),
+                                  _ptr(pset.priors), _ptr(pset.enc_zero), A, grid, float(thresh),
+                                  _ptr(o_cls), _ptr(o_loc), _ptr(o_mask), _ptr(owner), _ptr(wbuf), wbuf.numel(),
+                                  _stream()))
+    return o_cls, o_loc, o_mask
+
+
+def pack_gt(boxes_list, cls_list, device="cuda"):
+    """Concatenate per-image numpy gts into the (gt_box, gt_cls, gt_off, total, max_nt) batch form."""
+    counts = [int(np.shape(b)[0]) for b in boxes_list]
+    off = np.zeros(len(counts) + 1, np.int32)
+    off[1:] = np.cumsum(counts)
+    total = int(off[-1])
+    if total:
+        box = np.concatenate([np.asarray(b, np.float32).reshape(-1, 4) for b in boxes_list], 0)
+        cls = np.concatenate([np.asarray(c, np.float32).reshape(-1) for c in cls_list], 0)
+    else:
+        box, cls = np.zeros((0, 4), np.float32), np.zeros((0,), np.float32)
+    return (torch.from_numpy(box).to(device), torch.from_numpy(cls).to(device),
+            torch.from_numpy(off).to(device), total, max(counts) if counts else 0)
+
+
+def iou_n(b1, b2):
+    """ssd_iou_n: f32 [n,4] vs f64 [n,4] device tensors -> f64 [n]."""
+    L = _lib.lib()
+    _dev(b1, torch.float32)
+    _dev(b2, torch.float64)
+    n = b1.shape[0]
+    out = torch.empty((n,), dtype=torch.float64, device=b1.device)
+    _lib.check(L.ssd_iou_n(_ptr(b1), _ptr(b2), n, _ptr(out), _stream()))
+    return out
+
+
+def apply_anchor_box(box, priors):
+    """ssd_apply_anchor_box: f32 [n,4] vs f64 [n,4] device tensors -> f64 [n,4]."""
+    L = _lib.lib()
+    _dev(box, torch.float32)
+    _dev(priors, torch.float64)
+    n = box.shape[0]
+    out = torch.empty((n, 4), dtype=torch.float64, device=box.device)
+    _lib.check(L.ssd_apply_anchor_box(_ptr(box), _ptr(priors), n, _ptr(out), _stream()))
+    return out

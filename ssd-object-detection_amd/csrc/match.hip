@@ -95,16 +95,73 @@ struct GridHint {
     int cand_off[SSD_MAX_LEVELS + 1];       // prefix sum of k
 };
 
+// One record per gt row, produced by k_match_rows and read through the scalar cache by
+// k_match_pairs: float32-evaluated corners/area widened to f64, and the row pruning bound.
+struct __attribute__((aligned(16))) RowRec {
+    double lx, ly, hx, hy, a, lbm;
+};
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
+    const int lo = __shfl_xor(__double2loint(v), mask);
+    const int hi = __shfl_xor(__double2hiint(v), mask);
+    return __hiloint2double(hi, lo);
+}
+
 // ------------------------------------------------------------------------------------------------
-template <int CPT>
+// K0: per gt row (32 lanes each): corner record + an exact seed of the row maximum taken from the
+// priors of the cell under the gt centre on every level (geometry hint).  The seed L is the IoU
+// of a real column of this row, hence L <= row maximum; lbm = L*(1-2^-50) is the pruning bound.
+__global__ __launch_bounds__(WG) void k_match_rows(const float4* __restrict__ gt_box, int total_gt,
+                                                   const double* __restrict__ priors, int A, GridHint hint,
+                                                   RowRec* __restrict__ rows) {
+    const int gid = blockIdx.x * WG + threadIdx.x;
+    const int row = gid >> 5, sub = gid & 31;
+    const bool live = row < total_gt;
+    const float4 g = gt_box[live ? row : 0];
+    const Corner gc = gt_corner(g);
+    double best = 0.0;
+    if (hint.levels > 0) {
+        const int ncand = hint.cand_off[hint.levels];
+        for (int k = sub; k < ncand; k += 32) {
+            int l = 0;
+            while (l + 1 < hint.levels && k >= hint.cand_off[l + 1]) ++l;
+            int x = (int)floorf(g.x * (float)hint.gw[l]);
+            int y = (int)floorf(g.y * (float)hint.gh[l]);
+            x = min(max(x, 0), hint.gw[l] - 1);
+            y = min(max(y, 0), hint.gh[l] - 1);
+            int c = hint.col_off[l] + (y * hint.gw[l] + x) * hint.k[l] + (k - hint.cand_off[l]);
+            c = min(max(c, 0), A - 1);
+            const double2 lo = *reinterpret_cast<const double2*>(priors + 4 * (size_t)c);
+            const double2 hi = *reinterpret_cast<const double2*>(priors + 4 * (size_t)c + 2);
+            double inter, uni;
+            inter_union(gc, prior_corner(lo.x, lo.y, hi.x, hi.y), inter, uni);
+            const double q = inter / uni;
+            if (q > best) best = q;
+        }
+    }
+#pragma unroll
+    for (int m = 16; m > 0; m >>= 1) {
+        const double o = shfl_xor_f64(best, m);
+        if (o > best) best = o;
+    }
+    if (live && sub == 0) {
+        RowRec r;
+        r.lx = gc.lx; r.ly = gc.ly; r.hx = gc.hx; r.hy = gc.hy; r.a = gc.a;
+        r.lbm = best * SSD_MARGIN;
+        rows[row] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: the streaming kernel.  grid (chunks, B); thread = one prior column, loops over the image's gt
+// rows whose records arrive through the scalar cache (uniform address).  No division unless
+// inter >= bound*union (bound = min(column bound, row bound)).
 __global__ __launch_bounds__(WG) void k_match_pairs(
     const float4* __restrict__ gt_box, const float* __restrict__ gt_cls, const int* __restrict__ gt_off,
-    const double* __restrict__ priors, const float4* __restrict__ enc_zero, int A, double thresh,
-    GridHint hint, int* __restrict__ out_cls, float4* __restrict__ out_loc, uint8_t* __restrict__ out_mask,
-    int* __restrict__ out_owner, double* __restrict__ part_q, int* __restrict__ part_c, int nchunk) {
-    __shared__ Corner s_row[RT];
-    __shared__ double s_lbm[RT];
-    __shared__ unsigned long long s_seed[RT];
+    const RowRec* __restrict__ rows, const double* __restrict__ priors, const float4* __restrict__ enc_zero,
+    int A, double thresh, int* __restrict__ out_cls, float4* __restrict__ out_loc,
+    uint8_t* __restrict__ out_mask, int* __restrict__ out_owner, double* __restrict__ part_q,
+    int* __restrict__ part_c, int nchunk) {
     __shared__ double s_wq[NWAVE][RT];
     __shared__ int s_wc[NWAVE][RT];
 
@@ -112,94 +169,51 @@ __global__ __launch_bounds__(WG) void k_match_pairs(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g0 = gt_off[b];
     const int nt = gt_off[b + 1] - g0;
-    const int cbase = chunk * (WG * CPT);
+    const int c = chunk * WG + tid;
+    const bool valid = c < A;
+    const int cc = valid ? c : A - 1;
 
-    Corner pc[CPT];
-    double p4[CPT][4];
-    bool valid[CPT];
-    double cbq[CPT], cbm[CPT];
-    int cbr[CPT];
-#pragma unroll
-    for (int j = 0; j < CPT; ++j) {
-        const int c = cbase + j * WG + tid;
-        valid[j] = c < A;
-        const int cc = valid[j] ? c : A - 1;
-        const double2 lo = *reinterpret_cast<const double2*>(priors + 4 * (size_t)cc);
-        const double2 hi = *reinterpret_cast<const double2*>(priors + 4 * (size_t)cc + 2);
-        p4[j][0] = lo.x; p4[j][1] = lo.y; p4[j][2] = hi.x; p4[j][3] = hi.y;
-        pc[j] = prior_corner(lo.x, lo.y, hi.x, hi.y);
-        cbq[j] = thresh;                       // phase 2 needs max > thresh (utils/bbox.py:73)
-        cbm[j] = thresh * SSD_MARGIN;
-        cbr[j] = -1;
-    }
+    const double2 plo = *reinterpret_cast<const double2*>(priors + 4 * (size_t)cc);
+    const double2 phi = *reinterpret_cast<const double2*>(priors + 4 * (size_t)cc + 2);
+    const float4 ez = enc_zero[cc];
+    Corner pc = prior_corner(plo.x, plo.y, phi.x, phi.y);
+    double cbq = thresh;                       // phase 2 needs max > thresh (utils/bbox.py:73)
+    double cbm = thresh * SSD_MARGIN;
+    int cbr = -1;
 
     for (int t0 = 0; t0 < nt; t0 += RT) {
         const int nr = min(RT, nt - t0);
-        __syncthreads();
-        if (tid < nr) {
-            const float4 g = gt_box[g0 + t0 + tid];
-            s_row[tid] = gt_corner(g);
-            s_seed[tid] = 0ull;
-#pragma unroll
-            for (int w = 0; w < NWAVE; ++w) { s_wq[w][tid] = 0.0; s_wc[w][tid] = INT_MAX; }
-        }
-        __syncthreads();
-        // exact seeds of the row maxima from the cells under the gt centre (speed hint only)
-        if (hint.levels > 0) {
-            const int ncand = hint.cand_off[hint.levels];
-            for (int i = tid; i < nr * ncand; i += WG) {
-                const int r = i / ncand, k = i - r * ncand;
-                int l = 0;
-                while (l + 1 < hint.levels && k >= hint.cand_off[l + 1]) ++l;
-                const float4 g = gt_box[g0 + t0 + r];
-                int x = (int)floorf(g.x * (float)hint.gw[l]);
-                int y = (int)floorf(g.y * (float)hint.gh[l]);
-                x = min(max(x, 0), hint.gw[l] - 1);
-                y = min(max(y, 0), hint.gh[l] - 1);
-                int c = hint.col_off[l] + (y * hint.gw[l] + x) * hint.k[l] + (k - hint.cand_off[l]);
-                c = min(max(c, 0), A - 1);
-                const double2 lo = *reinterpret_cast<const double2*>(priors + 4 * (size_t)c);
-                const double2 hi = *reinterpret_cast<const double2*>(priors + 4 * (size_t)c + 2);
-                double inter, uni;
-                inter_union(s_row[r], prior_corner(lo.x, lo.y, hi.x, hi.y), inter, uni);
-                const double q = inter / uni;
-                if (q > 0.0) atomicMax(&s_seed[r], (unsigned long long)__double_as_longlong(q));
-            }
-        }
-        __syncthreads();
-        if (tid < nr) s_lbm[tid] = __longlong_as_double((long long)s_seed[tid]) * SSD_MARGIN;
-        __syncthreads();
-
+        if (t0) __syncthreads();               // previous tile's merge has read the slots
+        RowRec nxt = rows[g0 + t0];                    // uniform -> scalar loads, one row ahead
         for (int r = 0; r < nr; ++r) {
-            const Corner g = s_row[r];
-            const double lbm = s_lbm[r];
+            const RowRec g = nxt;
+            nxt = rows[g0 + t0 + min(r + 1, nr - 1)];
+            Corner gc;
+            gc.lx = g.lx; gc.ly = g.ly; gc.hx = g.hx; gc.hy = g.hy; gc.a = g.a;
+            double inter, uni;
+            inter_union(gc, pc, inter, uni);
+            const double bound = fmin(cbm, g.lbm);
+            const bool pass = valid && (inter >= bound * uni);
             double wbq = 0.0;                  // best row candidate of this wave (uniform)
             int wbc = INT_MAX;
-#pragma unroll
-            for (int j = 0; j < CPT; ++j) {
-                double inter, uni;
-                inter_union(g, pc[j], inter, uni);
-                const double bound = fmin(cbm[j], lbm);
-                const bool pass = valid[j] && (inter >= bound * uni);
-                if (__ballot(pass)) {          // rare: some lane needs the exact quotient
-                    double q = 0.0;
-                    bool rowcand = false;
-                    if (pass) {
-                        q = inter / uni;
-                        if (q > cbq[j]) { cbq[j] = q; cbr[j] = t0 + r; cbm[j] = q * SSD_MARGIN; }
-                        rowcand = q >= lbm;
-                    }
-                    unsigned long long m = __ballot(rowcand);
-                    while (m) {
-                        const int l = __ffsll((long long)m) - 1;
-                        const double ql = readlane_f64(q, l);
-                        const int cl = cbase + j * WG + (wave << 6) + l;
-                        if (better(ql, cl, wbq, wbc)) { wbq = ql; wbc = cl; }
-                        m &= m - 1;
-                    }
+            if (__ballot(pass)) {              // rare: some lane needs the exact quotient
+                double q = 0.0;
+                bool rowcand = false;
+                if (pass) {
+                    q = inter / uni;
+                    if (q > cbq) { cbq = q; cbr = t0 + r; cbm = q * SSD_MARGIN; }
+                    rowcand = q >= g.lbm;
+                }
+                unsigned long long m = __ballot(rowcand);
+                while (m) {
+                    const int l = __ffsll((long long)m) - 1;
+                    const double ql = readlane_f64(q, l);
+                    const int cl = chunk * WG + (wave << 6) + l;
+                    if (better(ql, cl, wbq, wbc)) { wbq = ql; wbc = cl; }
+                    m &= m - 1;
                 }
             }
-            if (lane == 0 && wbc != INT_MAX) { s_wq[wave][r] = wbq; s_wc[wave][r] = wbc; }
+            if (lane == 0) { s_wq[wave][r] = wbq; s_wc[wave][r] = wbc; }
         }
         __syncthreads();
         if (tid < nr) {
@@ -217,22 +231,19 @@ __global__ __launch_bounds__(WG) void k_match_pairs(
         }
     }
 
-    // phase-2 outputs for this thread's columns (phase-1 columns are patched by k_match_phase1)
-#pragma unroll
-    for (int j = 0; j < CPT; ++j) {
-        if (!valid[j]) continue;
-        const int c = cbase + j * WG + tid;
+    // phase-2 outputs for this thread's column (phase-1 columns are patched by k_match_phase1)
+    if (valid) {
         const size_t o = (size_t)b * A + c;
-        if (out_owner) out_owner[o] = cbr[j];
-        if (cbr[j] >= 0) {
-            const float4 g = gt_box[g0 + cbr[j]];
-            out_cls[o] = (int)gt_cls[g0 + cbr[j]];
+        if (out_owner) out_owner[o] = cbr;
+        if (cbr >= 0) {
+            const float4 g = gt_box[g0 + cbr];
+            out_cls[o] = (int)gt_cls[g0 + cbr];
             out_mask[o] = 1;
-            out_loc[o] = encode_row(g, p4[j][0], p4[j][1], p4[j][2], p4[j][3]);
+            out_loc[o] = encode_row(g, plo.x, plo.y, phi.x, phi.y);
         } else {
             out_cls[o] = 0;
             out_mask[o] = 0;
-            out_loc[o] = enc_zero[c];
+            out_loc[o] = ez;
         }
     }
 }
@@ -242,7 +253,7 @@ __global__ __launch_bounds__(WG) void k_match_pairs(
 __device__ __forceinline__ void wg_argmax(double& q, int& c, double* s_q, int* s_c) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        const double oq = __shfl_xor(q, off);
+        const double oq = shfl_xor_f64(q, off);
         const int oc = __shfl_xor(c, off);
         if (better(oq, oc, q, c)) { q = oq; c = oc; }
     }
@@ -278,13 +289,24 @@ __device__ __forceinline__ void row_scan(const Corner& g, const double* __restri
     c_out = bc;
 }
 
+constexpr int P1_LDS_ROWS = 512;               // row state lives in LDS up to this many gt rows
+
+// K2: sequential phase 1 (utils/bbox.py:62-68) per image + patch of the phase-1 columns.
+// Literal semantics: n_t rounds, each taking the largest remaining IoU (ties: lowest row, then
+// lowest column) and eliminating its row and column.  Executed as: while some still-free rows
+// share their best column, let the best-priority such row (the pivot) and every free row ahead of
+// it take their columns at once (none of those can be disturbed: nobody else wants their
+// columns), re-scan the rows that wanted the pivot's column over the untaken columns, repeat;
+// when no two free rows share a best column every row takes its own.
 __global__ __launch_bounds__(WG) void k_match_phase1(
     const float4* __restrict__ gt_box, const float* __restrict__ gt_cls, const int* __restrict__ gt_off,
     const double* __restrict__ priors, int A, int nchunk, const double* __restrict__ part_q,
-    const int* __restrict__ part_c, double* row_q, int* row_c, int* row_state,
-    int* __restrict__ out_cls, float4* __restrict__ out_loc, uint8_t* __restrict__ out_mask,
-    int* __restrict__ out_owner) {
-    extern __shared__ unsigned s_taken[];      // A-bit map of phase-1 columns
+    const int* __restrict__ part_c, double* g_rq, int* g_rc, int* g_rs, int* __restrict__ out_cls,
+    float4* __restrict__ out_loc, uint8_t* __restrict__ out_mask, int* __restrict__ out_owner) {
+    extern __shared__ unsigned s_bits[];       // 3 A-bit maps: taken | seen | dup
+    __shared__ double s_rq[P1_LDS_ROWS];
+    __shared__ int s_rc[P1_LDS_ROWS];
+    __shared__ int s_rs[P1_LDS_ROWS];
     __shared__ double s_q[NWAVE];
     __shared__ int s_c[NWAVE];
     __shared__ int s_flag;
@@ -292,8 +314,17 @@ __global__ __launch_bounds__(WG) void k_match_phase1(
     const int b = blockIdx.x, tid = threadIdx.x;
     const int g0 = gt_off[b];
     const int nt = gt_off[b + 1] - g0;
+    if (nt == 0) return;
     const int nwords = (A + 31) >> 5;
-    for (int i = tid; i < nwords; i += WG) s_taken[i] = 0u;
+    unsigned* taken = s_bits;
+    unsigned* seen = s_bits + nwords;
+    unsigned* dup = s_bits + 2 * nwords;
+    const bool in_lds = nt <= P1_LDS_ROWS;
+    double* rq = in_lds ? s_rq : g_rq + g0;    // generic pointers: LDS or global
+    int* rc = in_lds ? s_rc : g_rc + g0;
+    int* rs = in_lds ? s_rs : g_rs + g0;       // 1 = free, 0 = done
+
+    for (int i = tid; i < 3 * nwords; i += WG) s_bits[i] = 0u;
     if (tid == 0) s_flag = 0;
     __syncthreads();
 
@@ -302,63 +333,76 @@ __global__ __launch_bounds__(WG) void k_match_phase1(
         double bq = 0.0;
         int bc = INT_MAX;
         const size_t base = (size_t)(g0 + r) * nchunk;
+#pragma unroll 8
         for (int k = 0; k < nchunk; ++k) {
             const int c = part_c[base + k];
-            if (c != INT_MAX && better(part_q[base + k], c, bq, bc)) { bq = part_q[base + k]; bc = c; }
+            const double q = part_q[base + k];
+            if (c != INT_MAX && better(q, c, bq, bc)) { bq = q; bc = c; }
         }
-        row_q[g0 + r] = bq;
-        row_c[g0 + r] = bc;
-        row_state[g0 + r] = 1;                 // 1 = still free
+        rq[r] = bq;
+        rc[r] = bc;
+        rs[r] = 1;
         if (bc == INT_MAX) atomicOr(&s_flag, 2);
     }
     __syncthreads();
     if (s_flag & 2) {                          // a row without candidate (never for valid boxes): exact scan
         for (int r = 0; r < nt; ++r) {
-            if (row_c[g0 + r] != INT_MAX) continue;
+            if (rc[r] != INT_MAX) continue;
             double q; int c;
-            row_scan(gt_corner(gt_box[g0 + r]), priors, A, s_taken, q, c, s_q, s_c);
-            if (tid == 0) { row_q[g0 + r] = q; row_c[g0 + r] = c; }
+            row_scan(gt_corner(gt_box[g0 + r]), priors, A, taken, q, c, s_q, s_c);
+            __syncthreads();
+            if (tid == 0) { rq[r] = q; rc[r] = c; }
             __syncthreads();
         }
     }
-    // are the row-best columns pairwise distinct?
-    for (int r = tid; r < nt; r += WG) {
-        const int c = row_c[g0 + r];
-        const unsigned bit = 1u << (c & 31);
-        if (atomicOr(&s_taken[c >> 5], bit) & bit) atomicOr(&s_flag, 1);
+
+    for (int iter = 0; iter <= nt; ++iter) {
+        // which free rows share their best column with another free row?
+        for (int r = tid; r < nt; r += WG)
+            if (rs[r]) {
+                const int c = rc[r];
+                const unsigned bit = 1u << (c & 31);
+                if (atomicOr(&seen[c >> 5], bit) & bit) atomicOr(&dup[c >> 5], bit);
+            }
+        __syncthreads();
+        double pq = -1.0;
+        int pr = INT_MAX;
+        for (int r = tid; r < nt; r += WG)
+            if (rs[r]) {
+                const int c = rc[r];
+                if ((dup[c >> 5] >> (c & 31)) & 1u)
+                    if (better(rq[r], r, pq, pr)) { pq = rq[r]; pr = r; }
+            }
+        wg_argmax(pq, pr, s_q, s_c);
+        if (pr == INT_MAX) break;              // no sharing left: every free row keeps its column
+        const int cstar = rc[pr];
+        __syncthreads();
+        // pivot and every free row ahead of it take their columns; rows that wanted cstar re-scan
+        for (int r = tid; r < nt; r += WG)
+            if (rs[r]) {
+                const int c = rc[r];
+                if (r == pr || better(rq[r], r, pq, pr)) {
+                    rs[r] = 0;
+                    atomicOr(&taken[c >> 5], 1u << (c & 31));
+                } else if (c == cstar) {
+                    rs[r] = 2;                 // needs a re-scan
+                }
+            }
+        for (int i = tid; i < 2 * nwords; i += WG) seen[i] = 0u;   // seen and dup are adjacent
+        __syncthreads();
+        for (int r = 0; r < nt; ++r) {         // uniform; usually one row
+            if (rs[r] != 2) continue;
+            double q; int c;
+            row_scan(gt_corner(gt_box[g0 + r]), priors, A, taken, q, c, s_q, s_c);
+            __syncthreads();
+            if (tid == 0) { rq[r] = q; rc[r] = c; rs[r] = 1; }
+            __syncthreads();
+        }
     }
     __syncthreads();
-    if (s_flag & 1) {
-        // literal phase 1 (utils/bbox.py:62-68): n_t rounds of global argmax with row+column
-        // elimination; rows whose best column was just taken are re-scanned exactly.
-        for (int i = tid; i < nwords; i += WG) s_taken[i] = 0u;
-        __syncthreads();
-        for (int round = 0; round < nt; ++round) {
-            double bq = -1.0;
-            int br = INT_MAX;
-            for (int r = tid; r < nt; r += WG)
-                if (row_state[g0 + r] == 1 && better(row_q[g0 + r], r, bq, br)) { bq = row_q[g0 + r]; br = r; }
-            wg_argmax(bq, br, s_q, s_c);
-            const int cstar = row_c[g0 + br];
-            __syncthreads();
-            if (tid == 0) {
-                row_state[g0 + br] = 0;
-                s_taken[cstar >> 5] |= 1u << (cstar & 31);
-            }
-            __syncthreads();
-            for (int r = 0; r < nt; ++r) {     // uniform loop; conflicts are rare
-                if (row_state[g0 + r] != 1 || row_c[g0 + r] != cstar) continue;
-                double q; int c;
-                row_scan(gt_corner(gt_box[g0 + r]), priors, A, s_taken, q, c, s_q, s_c);
-                __syncthreads();
-                if (tid == 0) { row_q[g0 + r] = q; row_c[g0 + r] = c; }
-                __syncthreads();
-            }
-        }
-    }
     // patch the phase-1 columns (utils/bbox.py:84-90 scatter + apply_anchor_box)
     for (int r = tid; r < nt; r += WG) {
-        const int c = row_c[g0 + r];
+        const int c = rc[r];
         const size_t o = (size_t)b * A + c;
         const float4 g = gt_box[g0 + r];
         const double2 lo = *reinterpret_cast<const double2*>(priors + 4 * (size_t)c);
@@ -512,8 +556,7 @@ int ssd_iou_n(const float* b1, const double* b2, int n, double* out, void* strea
     return ssd_launch_status();
 }
 
-static constexpr int kMatchCPT = 1;
-static inline int match_nchunk(int A) { return (A + WG * kMatchCPT - 1) / (WG * kMatchCPT); }
+static inline int match_nchunk(int A) { return (A + WG - 1) / WG; }
 
 size_t ssd_match_encode_workspace_bytes(int B, int A, int total_gt) {
     (void)B;
@@ -521,9 +564,10 @@ size_t ssd_match_encode_workspace_bytes(int B, int A, int total_gt) {
     const size_t n = (size_t)(total_gt > 0 ? total_gt : 1);
     const size_t nchunk = (size_t)match_nchunk(A);
     size_t bytes = 0;
+    bytes += ssd_align_up(n * sizeof(RowRec), 256);            // row records
     bytes += ssd_align_up(n * nchunk * sizeof(double), 256);   // part_q
     bytes += ssd_align_up(n * nchunk * sizeof(int), 256);      // part_c
-    bytes += ssd_align_up(n * sizeof(double), 256);            // row_q
+    bytes += ssd_align_up(n * sizeof(double), 256);            // row_q   (only for n_t > 512)
     bytes += 2 * ssd_align_up(n * sizeof(int), 256);           // row_c, row_state
     return bytes;
 }
@@ -539,8 +583,8 @@ int ssd_match_encode(const float* gt_box, const float* gt_cls, const int32_t* gt
     if (!gt_off || !priors || !enc_zero || !out_cls || !out_loc || !out_mask) return SSD_ERR_VALUE;
     if (total_gt > 0 && (!gt_box || !gt_cls)) return SSD_ERR_VALUE;
     if (ws_bytes < ssd_match_encode_workspace_bytes(B, A, total_gt) || !ws) return SSD_ERR_WORKSPACE;
-    const size_t lds_bitmap = (size_t)((A + 31) / 32) * sizeof(unsigned);
-    if (lds_bitmap > 96 * 1024) return SSD_ERR_UNSUPPORTED;
+    const size_t lds_bitmaps = 3 * (size_t)((A + 31) / 32) * sizeof(unsigned);
+    if (lds_bitmaps > 128 * 1024) return SSD_ERR_UNSUPPORTED;
 
     GridHint hint;
     hint.levels = 0;
@@ -559,6 +603,7 @@ int ssd_match_encode(const float* gt_box, const float* gt_cls, const int32_t* gt
     const int nchunk = match_nchunk(A);
     const size_t n = (size_t)(total_gt > 0 ? total_gt : 1);
     char* p = static_cast<char*>(ws);
+    RowRec* rows = reinterpret_cast<RowRec*>(p);   p += ssd_align_up(n * sizeof(RowRec), 256);
     double* part_q = reinterpret_cast<double*>(p); p += ssd_align_up(n * nchunk * sizeof(double), 256);
     int* part_c = reinterpret_cast<int*>(p);       p += ssd_align_up(n * nchunk * sizeof(int), 256);
     double* row_q = reinterpret_cast<double*>(p);  p += ssd_align_up(n * sizeof(double), 256);
@@ -566,15 +611,22 @@ int ssd_match_encode(const float* gt_box, const float* gt_cls, const int32_t* gt
     int* row_state = reinterpret_cast<int*>(p);
 
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_match_pairs<kMatchCPT>, dim3(nchunk, B), dim3(WG), 0, s,
-                       reinterpret_cast<const float4*>(gt_box), gt_cls, gt_off, priors,
-                       reinterpret_cast<const float4*>(enc_zero), A, thresh, hint, out_cls,
+    if (total_gt > 0) {
+        hipLaunchKernelGGL(k_match_rows, dim3((total_gt * 32 + WG - 1) / WG), dim3(WG), 0, s,
+                           reinterpret_cast<const float4*>(gt_box), total_gt, priors, A, hint, rows);
+        if (hipGetLastError() != hipSuccess) return SSD_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(k_match_pairs, dim3(nchunk, B), dim3(WG), 0, s,
+                       reinterpret_cast<const float4*>(gt_box), gt_cls, gt_off, rows, priors,
+                       reinterpret_cast<const float4*>(enc_zero), A, thresh, out_cls,
                        reinterpret_cast<float4*>(out_loc), out_mask, out_owner, part_q, part_c, nchunk);
     if (hipGetLastError() != hipSuccess) return SSD_ERR_LAUNCH;
-    hipLaunchKernelGGL(k_match_phase1, dim3(B), dim3(WG), lds_bitmap, s,
-                       reinterpret_cast<const float4*>(gt_box), gt_cls, gt_off, priors, A, nchunk, part_q,
-                       part_c, row_q, row_c, row_state, out_cls, reinterpret_cast<float4*>(out_loc), out_mask,
-                       out_owner);
+    if (total_gt > 0) {
+        hipLaunchKernelGGL(k_match_phase1, dim3(B), dim3(WG), lds_bitmaps, s,
+                           reinterpret_cast<const float4*>(gt_box), gt_cls, gt_off, priors, A, nchunk, part_q,
+                           part_c, row_q, row_c, row_state, out_cls, reinterpret_cast<float4*>(out_loc),
+                           out_mask, out_owner);
+    }
     return ssd_launch_status();
 }
 

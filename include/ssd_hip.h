@@ -109,6 +109,26 @@ int ssd_apply_anchor_box(const float* box, const double* priors, int n, double* 
  * bit-exact.  Exposed for parity tests and for callers of iou_n. */
 int ssd_iou_n(const float* b1, const double* b2, int n, double* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training loss, forward + backward -- replaces SSDObjectDetectionModel._ssd_loss
+ * (models/ssd_model.py:341-396) and the part of tape.gradient (:248) that flows into the two
+ * network outputs.
+ *   conf      [B*A*C] class logits, background = class C-1 (:47,364-365); dtype SSD_F32 or SSD_BF16
+ *   loc       [B*A*4] predicted offsets, same dtype
+ *   gt_cls    int32[B*A], gt_loc float[B*A*4], gt_mask uint8[B*A]: the outputs of ssd_match_encode
+ *   grad_scale multiplies both gradients (1.0 = d total_loss)
+ *   out8      float[8]: loc loss, cls loss pos, cls loss neg (the reference's three scalars, :392-394),
+ *             their sum, P, N (= number of mined negatives, ties included :372), tau, status
+ *             (0 ok; 1 = P==0 or 3P > B*A, where TF would raise; 2 = tau==0, where the assert at :375 fires)
+ *   dconf     [B*A*C], dloc [B*A*4]: gradients, same dtype as conf/loc
+ * Hard-negative mining is global over the B images handed in (one micro-batch), as in the reference.
+ * fp32 losses agree with a float64 evaluation to <= 1e-4 relative.
+ * ---------------------------------------------------------------------------------------- */
+size_t ssd_loss_workspace_bytes(int B, int A, int C);
+int ssd_loss_fwd_bwd(const void* conf, const void* loc, int dtype, const int32_t* gt_cls,
+                     const float* gt_loc, const uint8_t* gt_mask, int B, int A, int C, float grad_scale,
+                     float* out8, void* dconf, void* dloc, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

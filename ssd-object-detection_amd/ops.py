@@ -154,3 +154,30 @@ def apply_anchor_box(box, priors):
     out = torch.empty((n, 4), dtype=torch.float64, device=box.device)
     _lib.check(L.ssd_apply_anchor_box(_ptr(box), _ptr(priors), n, _ptr(out), _stream()))
     return out
+
+
+_loss_ws = MatchWorkspace()
+
+
+def ssd_loss(conf, loc, gt_cls, gt_loc, gt_mask, grad_scale=1.0, ws=None):
+    """ssd_loss_fwd_bwd (replaces _ssd_loss, models/ssd_model.py:341-396, and its gradient).
+
+    conf [B,A,C], loc [B,A,4] (both f32 or both bf16); gt_* from match_encode.
+    Returns (out8 f32[8] device tensor, dconf, dloc).  out8 = loc, pos, neg, total, P, N, tau, status."""
+    L = _lib.lib()
+    B, A, C = conf.shape
+    assert conf.dtype == loc.dtype and conf.dtype in (torch.float32, torch.bfloat16)
+    assert conf.is_cuda and conf.is_contiguous() and loc.is_contiguous()
+    assert loc.shape == (B, A, 4) and gt_loc.shape == (B, A, 4)          # models/ssd_model.py:347-351
+    assert gt_cls.shape == (B, A) and gt_mask.shape == (B, A)
+    _dev(gt_cls, torch.int32); _dev(gt_loc, torch.float32); _dev(gt_mask, torch.uint8)
+    dtype = 0 if conf.dtype == torch.float32 else 1
+    out = torch.empty((8,), dtype=torch.float32, device=conf.device)
+    dconf = torch.empty_like(conf)
+    dloc = torch.empty_like(loc)
+    nbytes = L.ssd_loss_workspace_bytes(B, A, C)
+    wbuf = (ws or _loss_ws).get(nbytes, conf.device)
+    _lib.check(L.ssd_loss_fwd_bwd(_ptr(conf), _ptr(loc), dtype, _ptr(gt_cls), _ptr(gt_loc), _ptr(gt_mask), B, A, C,
+                                  float(grad_scale), _ptr(out), _ptr(dconf), _ptr(dloc), _ptr(wbuf), wbuf.numel(),
+                                  _stream()))
+    return out, dconf, dloc

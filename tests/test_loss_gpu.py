@@ -1,0 +1,129 @@
+"""GPU parity: fused SSD loss forward+backward (ssd_loss_fwd_bwd) vs the float64 oracle restatement of
+models/ssd_model.py:341-396.  Tolerance: 1e-4 relative on the fp32 loss scalars (north star);
+P and N exact; gradients 2e-5 absolute-relative mix for f32, bf16 rounding for bf16."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import ssd_oracle as O                                   # noqa: E402
+from tests.helpers import golden_priors                              # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import ssd_object_detection_amd.ops as ops_
+    return ops_
+
+
+def make_targets(ops, B, first=0, n_t=None):
+    from ssd_object_detection_amd.data_loaders.synthetic import synth_batch_gt
+    pset = ops.build_priors()
+    cls_l, box_l = synth_batch_gt(first, B, n_t)
+    gt_box, gt_cls, gt_off, total, max_nt = ops.pack_gt(box_l, cls_l)
+    return ops.match_encode(gt_box, gt_cls, gt_off, total, max_nt, pset, 0.5)
+
+
+def run_case(ops, conf, loc, cls, gloc, mask, rtol=1e-4, gtol=2e-5):
+    out, dconf, dloc = ops.ssd_loss(conf, loc, cls, gloc, mask)
+    out = out.cpu().numpy()
+    ref = O.ssd_loss(cls.cpu().numpy(), gloc.cpu().numpy(), mask.cpu().numpy(),
+                     loc.float().cpu().numpy(), conf.float().cpu().numpy(), want_grad=True)
+    assert out[7] == 0.0
+    assert int(out[4]) == ref["num_pos"]
+    for i, key in enumerate(["loc", "pos", "neg", "total"]):
+        assert abs(out[i] - ref[key]) <= rtol * abs(ref[key]), (key, out[i], ref[key])
+    # negatives: ties at tau are included (models/ssd_model.py:372); a 1-ulp difference in a key next to
+    # tau may move an anchor across the threshold, so allow a handful of flips
+    tau = out[6]
+    assert abs(tau - ref["tau"]) <= 1e-5 * max(1.0, abs(ref["tau"]))
+    assert abs(int(out[5]) - ref["num_neg"]) <= 2
+    d = dconf.float().cpu().numpy().astype(np.float64)
+    rows_ref = np.abs(ref["dcls"]).sum(-1) > 0
+    rows_got = np.abs(d).sum(-1) > 0
+    flips = rows_ref != rows_got
+    assert flips.sum() <= 2
+    same = ~flips
+    scale = np.abs(ref["dcls"]).max()
+    assert np.abs(d[same] - ref["dcls"][same]).max() <= gtol * scale + (0 if conf.dtype == torch.float32 else 4e-3 * scale)
+    dl = dloc.float().cpu().numpy().astype(np.float64)
+    lscale = np.abs(ref["dbox"]).max()
+    assert np.abs(dl - ref["dbox"]).max() <= (1e-6 if conf.dtype == torch.float32 else 4e-3) * lscale
+    return out, ref
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_loss_random_logits(ops, dtype):
+    B, A, C = 4, 8732, 81
+    cls, gloc, mask = make_targets(ops, B)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    conf = torch.randn((B, A, C), generator=g, device="cuda", dtype=torch.float32).to(dtype)
+    loc = (0.5 * torch.randn((B, A, 4), generator=g, device="cuda", dtype=torch.float32)).to(dtype)
+    run_case(ops, conf, loc, cls, gloc, mask)
+
+
+def test_loss_microbatch_of_default_yml(ops):
+    # split_train.batch_size = 4 of the reference's config/default.yml:40-42: B=4 micro-batch, plus B=1
+    for B in (1, 3):
+        cls, gloc, mask = make_targets(ops, B, first=40 + B)
+        g = torch.Generator(device="cuda").manual_seed(B)
+        conf = 3.0 * torch.randn((B, 8732, 81), generator=g, device="cuda")
+        conf[..., 80] += 2.0                       # background-heavy, like a trained net
+        loc = torch.randn((B, 8732, 4), generator=g, device="cuda")
+        run_case(ops, conf, loc, cls, gloc, mask)
+
+
+def test_loss_ties_at_threshold(ops):
+    """All-equal logits: every background CE is identical, tau equals it, and `>=` keeps every
+    non-positive anchor (more than 3P of them)."""
+    B, A, C = 2, 8732, 81
+    cls, gloc, mask = make_targets(ops, B, first=9)
+    conf = torch.zeros((B, A, C), device="cuda")
+    loc = torch.zeros((B, A, 4), device="cuda")
+    out, dconf, dloc = ops.ssd_loss(conf, loc, cls, gloc, mask)
+    out = out.cpu().numpy()
+    P = int(mask.sum())
+    assert int(out[4]) == P and int(out[5]) == B * A - P and out[7] == 0
+    np.testing.assert_allclose(out[1], np.log(81.0), rtol=1e-6)
+    np.testing.assert_allclose(out[2], np.log(81.0), rtol=1e-6)
+    ref = O.ssd_loss(cls.cpu().numpy(), gloc.cpu().numpy(), mask.cpu().numpy(), loc.cpu().numpy(), conf.cpu().numpy())
+    np.testing.assert_allclose(out[0], ref["loc"], rtol=1e-5)
+
+
+def test_loss_status_codes(ops):
+    A, C = 256, 81
+    conf = torch.randn((1, A, C), device="cuda")
+    loc = torch.randn((1, A, 4), device="cuda")
+    cls = torch.zeros((1, A), dtype=torch.int32, device="cuda")
+    gloc = torch.zeros((1, A, 4), device="cuda")
+    mask = torch.zeros((1, A), dtype=torch.uint8, device="cuda")
+    out, _, _ = ops.ssd_loss(conf, loc, cls, gloc, mask)
+    assert out.cpu().numpy()[7] == 1.0                        # P == 0: TF top_k(k=0)[-1] / division by zero
+    mask[0, :100] = 1                                         # 3P = 300 > 256 anchors: TF top_k raises
+    out, _, _ = ops.ssd_loss(conf, loc, cls, gloc, mask)
+    assert out.cpu().numpy()[7] == 1.0
+    mask[0, 70:] = 0                                          # P = 70, k = 210 > 186 negatives -> tau = 0
+    out, _, _ = ops.ssd_loss(conf, loc, cls, gloc, mask)
+    assert out.cpu().numpy()[7] == 2.0                        # reference assert at models/ssd_model.py:375
+
+
+def test_loss_full_config_properties(ops):
+    """BASELINE config 2 size (B=32, bf16): size-independent properties of the gradient."""
+    B, A, C = 32, 8732, 81
+    cls, gloc, mask = make_targets(ops, B, first=100)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    conf = torch.randn((B, A, C), generator=g, device="cuda").to(torch.bfloat16)
+    loc = torch.randn((B, A, 4), generator=g, device="cuda").to(torch.bfloat16)
+    out, dconf, dloc = ops.ssd_loss(conf, loc, cls, gloc, mask)
+    o = out.cpu().numpy()
+    P, N = int(o[4]), int(o[5])
+    assert P == int(mask.sum()) and N >= 3 * P and o[7] == 0
+    d = dconf.float()
+    nz = (d.abs().sum(-1) > 0)
+    assert int(nz.sum()) == P + N                                # exactly the selected rows carry gradient
+    assert float(d.sum(-1).abs().max()) < 2e-2 / P               # softmax - onehot sums to ~0 per row (bf16 rounding)
+    assert int((dloc.float().abs().sum(-1) > 0).sum()) <= P
+    # determinism: bitwise identical on a second run
+    out2, dconf2, _ = ops.ssd_loss(conf, loc, cls, gloc, mask)
+    assert torch.equal(out, out2) and torch.equal(dconf, dconf2)

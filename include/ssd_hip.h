@@ -129,6 +129,29 @@ int ssd_loss_fwd_bwd(const void* conf, const void* loc, int dtype, const int32_t
                      const float* gt_loc, const uint8_t* gt_mask, int B, int A, int C, float grad_scale,
                      float* out8, void* dconf, void* dloc, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Inference scoring + decode -- replaces the scoring half of SSDObjectDetectionModel.visualize
+ * (models/ssd_model.py:479-488, mask=None branch) and the box decode of visualize_dataset (:466-467).
+ *   conf [B*A*C], loc [B*A*4] (SSD_F32 / SSD_BF16), priors double[A*4]
+ *   score  float[B*A]  best non-background softmax probability
+ *   cls    int32[B*A]  its class (== argmax over all classes wherever cand is set)
+ *   box    float[B*A*4] decoded (cx,cy,w,h) in pixels (in_size = 300) for candidates, 0 elsewhere
+ *   cand   uint8[B*A]  score > score_thresh && !(p_background > score_thresh)
+ * ---------------------------------------------------------------------------------------- */
+int ssd_score_decode(const void* conf, const void* loc, int dtype, const double* priors, int B, int A, int C,
+                     float score_thresh, double in_size, float* score, int32_t* cls, float* box,
+                     uint8_t* cand, void* stream);
+
+/* Per-image, per-class greedy hard NMS.  The reference has NO suppression step; this
+ * entry point is build-defined and its oracle is oracle/ssd_oracle.py:nms.  Candidates (cand != 0) are
+ * ordered by (score desc, anchor asc); the first max_cand (<= ssd_nms_max_candidates()) take part; a
+ * candidate is kept iff its IoU -- the reference's scalar iou (utils/bbox.py:6-25) evaluated in float32 --
+ * with every already kept candidate of its class is <= iou_thresh.
+ *   keep uint8[B*A] (fully written), keep_count int32[B] or NULL.  Bit-exact against the oracle. */
+int ssd_nms_max_candidates(void);
+int ssd_nms(const float* score, const int32_t* cls, const float* box, const uint8_t* cand, int B, int A,
+            float iou_thresh, int max_cand, uint8_t* keep, int32_t* keep_count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,10 @@ _SIGNATURES = {
                                         ctypes.POINTER(PriorGrid), ctypes.c_double, VP, VP, VP, VP, VP, ctypes.c_size_t, VP]),
     "ssd_apply_anchor_box": (ctypes.c_int, [VP, VP, ctypes.c_int, VP, VP]),
     "ssd_iou_n": (ctypes.c_int, [VP, VP, ctypes.c_int, VP, VP]),
+    "ssd_score_decode": (ctypes.c_int, [VP, VP, ctypes.c_int, VP, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_float, ctypes.c_double, VP, VP, VP, VP, VP]),
+    "ssd_nms_max_candidates": (ctypes.c_int, []),
+    "ssd_nms": (ctypes.c_int, [VP, VP, VP, VP, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, VP, VP, VP]),
     "ssd_loss_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "ssd_loss_fwd_bwd": (ctypes.c_int, [VP, VP, ctypes.c_int, VP, VP, VP, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_float, VP, VP, VP, VP, ctypes.c_size_t, VP]),

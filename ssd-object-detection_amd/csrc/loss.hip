@@ -18,6 +18,7 @@
 // fixed-order partial sums only).
 #include "common.h"
 #include <hip/hip_bf16.h>
+#include "rowblock.h"
 
 namespace {
 
@@ -71,50 +72,6 @@ inline size_t loss_ws_layout(size_t n, char* base, LossWs* w) {
         w->zero_bytes = zero_end - zero_start;
     }
     return off;
-}
-
-template <typename T> __device__ __forceinline__ float to_f32(T v);
-template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
-template <> __device__ __forceinline__ float to_f32<__hip_bfloat16>(__hip_bfloat16 v) { return __bfloat162float(v); }
-template <typename T> __device__ __forceinline__ T from_f32(float v);
-template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
-template <> __device__ __forceinline__ __hip_bfloat16 from_f32<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
-
-// Stage `count` contiguous elements starting at src (16-byte aligned) into LDS as float, coalesced
-// 16 B per lane, STAGE_DEPTH loads in flight per lane before the first LDS write.
-constexpr int STAGE_DEPTH = 12;
-template <typename T>
-__device__ __forceinline__ void stage_block(const T* __restrict__ src, size_t count, float* lds) {
-    constexpr int PER = 16 / sizeof(T);
-    const size_t nvec = count / PER;
-    const uint4* v = reinterpret_cast<const uint4*>(src);
-    for (size_t base = 0; base < nvec; base += (size_t)STAGE_DEPTH * WG) {
-        uint4 raw[STAGE_DEPTH];
-#pragma unroll
-        for (int j = 0; j < STAGE_DEPTH; ++j) {
-            const size_t i = base + (size_t)j * WG + threadIdx.x;
-            if (i < nvec) raw[j] = v[i];
-        }
-#pragma unroll
-        for (int j = 0; j < STAGE_DEPTH; ++j) {
-            const size_t i = base + (size_t)j * WG + threadIdx.x;
-            if (i >= nvec) continue;
-            if constexpr (sizeof(T) == 4) {
-                *reinterpret_cast<uint4*>(lds + i * 4) = raw[j];
-            } else {
-                const unsigned w[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
-                float f[8];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    f[2 * k] = __uint_as_float(w[k] << 16);
-                    f[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
-                }
-                *reinterpret_cast<float4*>(lds + i * 8) = make_float4(f[0], f[1], f[2], f[3]);
-                *reinterpret_cast<float4*>(lds + i * 8 + 4) = make_float4(f[4], f[5], f[6], f[7]);
-            }
-        }
-    }
-    for (size_t i = nvec * PER + threadIdx.x; i < count; i += WG) lds[i] = to_f32<T>(src[i]);
 }
 
 __device__ __forceinline__ double block_sum(double v, double* s_red) {

@@ -181,3 +181,34 @@ def ssd_loss(conf, loc, gt_cls, gt_loc, gt_mask, grad_scale=1.0, ws=None):
                                   float(grad_scale), _ptr(out), _ptr(dconf), _ptr(dloc), _ptr(wbuf), wbuf.numel(),
                                   _stream()))
     return out, dconf, dloc
+
+
+def score_decode(conf, loc, pset, score_thresh=0.5, in_size=300.0):
+    """ssd_score_decode (replaces visualize's scoring, models/ssd_model.py:479-488, + decode :466-467).
+    Returns (score f32[B,A], cls i32[B,A], box f32[B,A,4] pixels, cand u8[B,A])."""
+    L = _lib.lib()
+    B, A, C = conf.shape
+    assert conf.dtype == loc.dtype and conf.dtype in (torch.float32, torch.bfloat16)
+    assert conf.is_cuda and conf.is_contiguous() and loc.is_contiguous() and A == pset.A
+    dev = conf.device
+    score = torch.empty((B, A), dtype=torch.float32, device=dev)
+    cls = torch.empty((B, A), dtype=torch.int32, device=dev)
+    box = torch.empty((B, A, 4), dtype=torch.float32, device=dev)
+    cand = torch.empty((B, A), dtype=torch.uint8, device=dev)
+    _lib.check(L.ssd_score_decode(_ptr(conf), _ptr(loc), 0 if conf.dtype == torch.float32 else 1, _ptr(pset.priors),
+                                  B, A, C, float(score_thresh), float(in_size), _ptr(score), _ptr(cls), _ptr(box),
+                                  _ptr(cand), _stream()))
+    return score, cls, box, cand
+
+
+def nms(score, cls, box, cand, iou_thresh=0.45, max_cand=400, want_count=False):
+    """ssd_nms: per-image per-class greedy NMS (build-defined; the reference has none).
+    Returns keep u8[B,A] (and keep_count i32[B] if want_count)."""
+    L = _lib.lib()
+    B, A = score.shape
+    _dev(score, torch.float32); _dev(cls, torch.int32); _dev(box, torch.float32); _dev(cand, torch.uint8)
+    keep = torch.empty((B, A), dtype=torch.uint8, device=score.device)
+    count = torch.empty((B,), dtype=torch.int32, device=score.device) if want_count else None
+    _lib.check(L.ssd_nms(_ptr(score), _ptr(cls), _ptr(box), _ptr(cand), B, A, float(iou_thresh), int(max_cand),
+                         _ptr(keep), _ptr(count), _stream()))
+    return (keep, count) if want_count else keep

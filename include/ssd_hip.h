@@ -152,6 +152,47 @@ int ssd_nms_max_candidates(void);
 int ssd_nms(const float* score, const int32_t* cls, const float* box, const uint8_t* cand, int B, int A,
             float iou_thresh, int max_cand, uint8_t* keep, int32_t* keep_count, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Convolution stack (NHWC bf16 activations, bf16 weights [Cout][k][k][Cin], fp32 accumulate on MFMA).
+ * Replaces the TensorFlow kernels behind SSDObjectDetectionModel._build (models/ssd_model.py:74-171)
+ * and behind tape.gradient (:248) for those layers.  TF "SAME" padding is passed explicitly:
+ * pad_total = max((Ho-1)*stride + k - H, 0), pad_t = pad_total/2 (the remainder goes after).
+ * Channel counts of activation tensors must be multiples of 8 (the 3-channel image is expanded to 8
+ * zero-padded channels by ssd_image_prep).
+ * ---------------------------------------------------------------------------------------- */
+/* y[B,Ho,Wo,Cout] = relu?(conv(x[B,H,W,Cin], w) + bias)          Conv2D, :86-151 and the VGG blocks :77-82 */
+int ssd_conv2d_fwd(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin,
+                   int Cout, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int relu, void* stream);
+/* One pyramid level's loc+conf heads as ONE 3x3 SAME GEMM (N = per_cell*(4+classes); weight rows: loc filters
+ * then conf filters), written straight into the concatenated outputs loc[B,A,4] / conf[B,A,classes]
+ * (:155-167: the Reshape + Concatenate are the store addressing). */
+int ssd_conv2d_head_fwd(const void* x, const void* w, const float* bias, void* loc, void* conf, int B, int H, int W,
+                        int Cin, int per_cell, int classes, int anchors_total, int level_off, void* stream);
+/* dx[B,H,W,Cin] (+)= conv_transpose(dy[B,Ho,Wo,Cout_pad], w_t), then zeroed where relu_src <= 0 (relu_src =
+ * the forward activation stored in dx's place, or NULL).  w_t from ssd_weight_transpose. */
+int ssd_conv2d_bwd_data(const void* dy, const void* w_t, const void* relu_src, void* dx, int B, int H, int W, int Cin,
+                        int Cout_pad, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int accumulate,
+                        void* stream);
+/* dw f32 [Cout][k][k][Cin], dbias f32 [Cout] (or NULL) from x[B,H,W,Cin] and dy[B,Ho,Wo,ldy] (first Cout
+ * channels).  Deterministic (fixed-order split reduction). */
+size_t ssd_conv2d_bwd_weight_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ldy, int ksize);
+int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias, int B, int H, int W, int Cin,
+                          int Cout, int ldy, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, void* ws,
+                          size_t ws_bytes, void* stream);
+/* w bf16 [Cout][k][k][Cin] -> w_t bf16 [Cin][k][k][Cout_pad], spatially flipped (data-gradient operand) */
+int ssd_weight_transpose(const void* w, void* w_t, int Cout, int ksize, int Cin, int Cout_pad, void* stream);
+int ssd_cast_bf16(const float* src, void* dst, long long n, void* stream);
+/* image f32 [B,H,W,3] -> bf16 [B,H,W,8]; normalize != 0 applies (x-0.5)*2 (models/ssd_model.py:214) */
+int ssd_image_prep(const float* img, void* out, int B, int H, int W, int normalize, void* stream);
+/* MaxPool2D 2x2 stride 2 (VGG block pools: VALID; models/ssd_model.py:84: SAME -> Ho = ceil(H/2)) */
+int ssd_maxpool2x2_fwd(const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, void* stream);
+/* pooling backward fused with the ReLU backward of the layer that produced x */
+int ssd_maxpool2x2_bwd(const void* x, const void* y, const void* dy, void* dx, int B, int H, int W, int C, int Ho,
+                       int Wo, void* stream);
+/* dloc[B,A,4], dconf[B,A,classes] (bf16) -> one level's padded NHWC head gradient [B, hw, npad] */
+int ssd_head_grad_pack(const void* dloc, const void* dconf, void* out, int B, int hw, int per_cell, int classes,
+                       int npad, int anchors_total, int level_off, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,17 @@ _SIGNATURES = {
                                         ctypes.c_float, ctypes.c_double, VP, VP, VP, VP, VP]),
     "ssd_nms_max_candidates": (ctypes.c_int, []),
     "ssd_nms": (ctypes.c_int, [VP, VP, VP, VP, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, VP, VP, VP]),
+    "ssd_conv2d_fwd": (ctypes.c_int, [VP, VP, VP, VP] + [ctypes.c_int] * 12 + [VP]),
+    "ssd_conv2d_head_fwd": (ctypes.c_int, [VP, VP, VP, VP, VP] + [ctypes.c_int] * 8 + [VP]),
+    "ssd_conv2d_bwd_data": (ctypes.c_int, [VP, VP, VP, VP] + [ctypes.c_int] * 12 + [VP]),
+    "ssd_conv2d_bwd_weight_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 7),
+    "ssd_conv2d_bwd_weight": (ctypes.c_int, [VP, VP, VP, VP] + [ctypes.c_int] * 12 + [VP, ctypes.c_size_t, VP]),
+    "ssd_weight_transpose": (ctypes.c_int, [VP, VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, VP]),
+    "ssd_cast_bf16": (ctypes.c_int, [VP, VP, ctypes.c_longlong, VP]),
+    "ssd_image_prep": (ctypes.c_int, [VP, VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, VP]),
+    "ssd_maxpool2x2_fwd": (ctypes.c_int, [VP, VP] + [ctypes.c_int] * 6 + [VP]),
+    "ssd_maxpool2x2_bwd": (ctypes.c_int, [VP, VP, VP, VP] + [ctypes.c_int] * 6 + [VP]),
+    "ssd_head_grad_pack": (ctypes.c_int, [VP, VP, VP] + [ctypes.c_int] * 7 + [VP]),
     "ssd_loss_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "ssd_loss_fwd_bwd": (ctypes.c_int, [VP, VP, ctypes.c_int, VP, VP, VP, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_float, VP, VP, VP, VP, ctypes.c_size_t, VP]),

@@ -1,0 +1,733 @@
+// Convolution stack for gfx950 (MI355X): NHWC bf16 implicit-GEMM convolutions on MFMA.
+//
+// Replaces the TensorFlow kernels behind SSDObjectDetectionModel._build (models/ssd_model.py:74-171)
+// and their autodiff (tape.gradient, :248): Conv2D 3x3/1x1 (+bias, +ReLU) forward, data gradient
+// and weight gradient, and 2x2 max-pooling forward/backward.  TF "SAME" padding is asymmetric for
+// stride 2 (pad_before = pad_total/2, the remainder after) and is passed explicitly as (pad_t, pad_l).
+//
+//   k_conv_igemm   forward AND data-gradient: out[m][n] = sum_k A[m][k] * Wm[n][k].
+//                  A is gathered on the fly from an NHWC tensor: GEMM row m = output pixel (b,oy,ox),
+//                  k = (tap, channel); the source pixel of a tap is (o*mul + k - pad) / div, taken only
+//                  when divisible and in range (zero otherwise).  Forward: mul = stride, div = 1.
+//                  Data gradient: the same kernel run on dY with the spatially flipped, transposed
+//                  weights ([Cin][kh][kw][Cout], made by k_weight_transpose), mul = 1, div = stride,
+//                  pad = k-1-pad: one code path for stride 1 and 2.
+//                  Tile 128 pixels x BN channels x 64 (k); 4 waves (2x2), each 64 x BN/2 as 16x16x32
+//                  bf16 MFMAs with weights as the A operand, so a lane ends up with 4 consecutive output
+//                  channels of one pixel (8-byte NHWC stores).  Global->register->LDS staging, one tile
+//                  ahead (loads issued before the MFMAs of the current tile, LDS written after them, one
+//                  barrier per k-step), XOR-swizzled 16-byte slots so ds_read_b128 is conflict-free.
+//   k_conv_wgrad   dW[co][(tap,ci)] = sum_pixels dY[pix][co] * X[src(pix,tap)][ci]: both operands are
+//                  "k-major" in memory, so tiles are staged as [pixel][channel] and the fragments are
+//                  fetched with the transposing LDS read ds_read_b64_tr_b16.  Split over pixel ranges
+//                  (grid.z); fp32 partial slabs are summed in fixed order (deterministic) by
+//                  k_wgrad_reduce.  The bias gradient rides along as an extra MFMA against a B fragment
+//                  of ones.
+#include "common.h"
+#include <hip/hip_bf16.h>
+
+namespace {
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4_t;
+typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s16x4_t;
+typedef unsigned short bf16_raw;
+
+constexpr int WG = 256;
+
+struct FastDiv {                             // exact n / d for 0 <= n < 2^31
+    unsigned mg;
+    int sh;                                  // sh < 0: d == 1
+    int d;
+};
+
+inline FastDiv make_fastdiv(int d) {
+    FastDiv f;
+    f.d = d;
+    if (d <= 1) { f.mg = 0; f.sh = -1; return f; }
+    int l = 0;
+    while ((1ll << l) < d) ++l;
+    const int s = 31 + l;
+    f.mg = (unsigned)(((1ull << s) + (unsigned long long)d - 1) / (unsigned long long)d);
+    f.sh = s - 32;
+    return f;
+}
+
+__device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
+    return f.sh < 0 ? n : (int)(__umulhi((unsigned)n, f.mg) >> f.sh);
+}
+
+struct ConvGeom {
+    int B, H, W, C;                          // source tensor (NHWC), C % 8 == 0
+    int Ho, Wo, N;                           // destination spatial dims and channel count (GEMM N)
+    int KH, KW;
+    int mul, div, pad_t, pad_l;              // source coordinate = (o*mul + k - pad) / div
+    int M;                                   // B*Ho*Wo
+    int nchunks;                             // KH*KW*C/8  (16-byte k chunks)
+    int ldw;                                 // weight row stride (elements) = KH*KW*C
+    int cpt;                                 // chunks per tap = C/8
+    FastDiv d_hw, d_w;                       // divide by Ho*Wo and by Wo
+};
+
+enum { EPI_FWD = 0, EPI_HEAD = 1, EPI_DGRAD = 2 };
+
+struct Epilogue {
+    const float* bias;                       // [N] or null                       (FWD, HEAD)
+    int relu;                                //                                    (FWD)
+    bf16_raw* out;                           // [M][ldo]                           (FWD, DGRAD)
+    int ldo;
+    const bf16_raw* mask_src;                // DGRAD: zero where mask_src <= 0 (ReLU backward), may be null
+    int accumulate;                          // DGRAD: out += result
+    // HEAD: columns [0,n_loc) -> loc, [n_loc, n_loc+n_conf) -> conf, in the reference's concatenated layout
+    bf16_raw* loc;
+    bf16_raw* conf;
+    int n_loc, n_conf;                       // per pixel: n*4 and n*C
+    int anchors_total;                       // A
+    int level_off;                           // first anchor of this level
+    int per_cell;                            // n
+    int classes;                             // C
+};
+
+__device__ __forceinline__ float bf2f(bf16_raw v) { return __uint_as_float((unsigned)v << 16); }
+__device__ __forceinline__ bf16_raw f2bf(float f) {
+    const __hip_bfloat16 h = __float2bfloat16(f);
+    return *reinterpret_cast<const bf16_raw*>(&h);
+}
+
+// LDS slot of 16-byte chunk `chunk` (0..7) of tile row `row`: two rows share one 256-byte bank row,
+// slots XOR-swizzled so that 16 consecutive rows reading the same chunk hit 16 different slots.
+__device__ __forceinline__ int swz(int row, int chunk) {
+    return (row >> 1) * 256 + ((((row & 1) << 3) | (chunk ^ ((row >> 1) & 7))) << 4);
+}
+
+template <int BN, int EPI>
+__global__ __launch_bounds__(WG) void k_conv_igemm(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ w,
+                                                   ConvGeom g, Epilogue ep) {
+    constexpr int BM = 128;
+    constexpr int CT = BN / 32;              // 16-wide channel tiles per wave
+    constexpr int PT = 4;                    // 16-wide pixel tiles per wave
+    constexpr int WROWS = BN / 32;           // weight rows staged per thread
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    auto s_x = [&](int buf) { return smem + buf * ((BM + BN) * 128); };
+    auto s_w = [&](int buf) { return smem + buf * ((BM + BN) * 128) + BM * 128; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave & 1, wave_n = wave >> 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int slot = tid & 7, r0 = tid >> 3;
+
+    // per-thread staging rows
+    int ybase[4], xbase[4];
+    long long ibase[4];
+    bool mvalid[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + r0 + 32 * j;
+        mvalid[j] = m < g.M;
+        const int mm = mvalid[j] ? m : 0;
+        const int b = fdiv(mm, g.d_hw);
+        const int rem = mm - b * g.d_hw.d;
+        const int oy = fdiv(rem, g.d_w);
+        const int ox = rem - oy * g.d_w.d;
+        ybase[j] = oy * g.mul - g.pad_t;
+        xbase[j] = ox * g.mul - g.pad_l;
+        ibase[j] = (long long)b * g.H * g.W;
+    }
+    // k state of this thread's chunk slot
+    int tap = slot / g.cpt, cc = slot - tap * g.cpt;
+    int kh = tap / g.KW, kw = tap - kh * g.KW;
+    int q = slot;
+
+    uint4 rx[4], rw[WROWS];
+    auto load_tiles = [&]() {
+        const bool kvalid = q < g.nchunks;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int ny = ybase[j] + kh, nx = xbase[j] + kw;
+            bool ok = kvalid && mvalid[j];
+            int iy = ny, ix = nx;
+            if (g.div > 1) {
+                ok = ok && ny >= 0 && nx >= 0 && (ny % g.div == 0) && (nx % g.div == 0);
+                iy = ny / g.div;
+                ix = nx / g.div;
+            }
+            ok = ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+            rx[j] = make_uint4(0, 0, 0, 0);
+            if (ok) rx[j] = *reinterpret_cast<const uint4*>(x + ((ibase[j] + (long long)iy * g.W + ix) * g.C + cc * 8));
+        }
+#pragma unroll
+        for (int j = 0; j < WROWS; ++j) {
+            const int n = n0 + r0 + 32 * j;
+            rw[j] = make_uint4(0, 0, 0, 0);
+            if (kvalid && n < g.N) rw[j] = *reinterpret_cast<const uint4*>(w + ((long long)n * g.ldw + (long long)q * 8));
+        }
+        // advance to the next k-step (8 chunks ahead)
+        q += 8;
+        cc += 8;
+        while (cc >= g.cpt) {
+            cc -= g.cpt;
+            if (++kw == g.KW) { kw = 0; ++kh; }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<uint4*>(s_x(buf) + swz(r0 + 32 * j, slot)) = rx[j];
+#pragma unroll
+        for (int j = 0; j < WROWS; ++j) *reinterpret_cast<uint4*>(s_w(buf) + swz(r0 + 32 * j, slot)) = rw[j];
+    };
+
+    f32x4_t acc[CT][PT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int p = 0; p < PT; ++p) acc[c][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nks = (g.nchunks + 7) >> 3;
+    load_tiles();
+    store_tiles(0);
+    __syncthreads();
+    const int frow = lane & 15, fk = lane >> 4;
+    for (int ks = 0; ks < nks; ++ks) {
+        const int cur = ks & 1;
+        const bool more = ks + 1 < nks;
+        if (more) load_tiles();
+#pragma unroll
+        for (int ksub = 0; ksub < 2; ++ksub) {
+            bf16x8_t fx[PT], fw[CT];
+#pragma unroll
+            for (int p = 0; p < PT; ++p)
+                fx[p] = *reinterpret_cast<const bf16x8_t*>(s_x(cur) + swz(wave_m * 64 + p * 16 + frow, ksub * 4 + fk));
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+                fw[c] = *reinterpret_cast<const bf16x8_t*>(s_w(cur) + swz(wave_n * (BN / 2) + c * 16 + frow, ksub * 4 + fk));
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int p = 0; p < PT; ++p)
+                    acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[c], fx[p], acc[c][p], 0, 0, 0);
+        }
+        if (more) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane holds channels n_base + (lane>>4)*4 + {0..3} of pixel m_base + (lane&15)
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const int m = m0 + wave_m * 64 + p * 16 + (lane & 15);
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int n = n0 + wave_n * (BN / 2) + c * 16 + (lane >> 4) * 4;
+            if (n >= g.N) continue;
+            float v[4] = {acc[c][p][0], acc[c][p][1], acc[c][p][2], acc[c][p][3]};
+            if constexpr (EPI == EPI_FWD) {
+                if (ep.bias) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (n + j < g.N) v[j] += ep.bias[n + j];
+                }
+                if (ep.relu) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                }
+                bf16_raw* o = ep.out + (long long)m * ep.ldo + n;
+                if (n + 3 < g.N) {
+                    *reinterpret_cast<uint2*>(o) = make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16),
+                                                              (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (n + j < g.N) o[j] = f2bf(v[j]);
+                }
+            } else if constexpr (EPI == EPI_DGRAD) {
+                bf16_raw* o = ep.out + (long long)m * ep.ldo + n;
+                const bf16_raw* ms = ep.mask_src ? ep.mask_src + (long long)m * ep.ldo + n : nullptr;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (n + j >= g.N) continue;
+                    float r = v[j];
+                    if (ep.accumulate) r += bf2f(o[j]);
+                    if (ms && !(bf2f(ms[j]) > 0.f)) r = 0.f;
+                    o[j] = f2bf(r);
+                }
+            } else {  // EPI_HEAD: scatter into loc [B][A][4] and conf [B][A][classes]
+                const int b = fdiv(m, g.d_hw);
+                const int pix = m - b * g.d_hw.d;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int nn = n + j;
+                    if (nn >= ep.n_loc + ep.n_conf) continue;
+                    const float r = v[j] + (ep.bias ? ep.bias[nn] : 0.f);
+                    const long long anchor0 = (long long)b * ep.anchors_total + ep.level_off + (long long)pix * ep.per_cell;
+                    if (nn < ep.n_loc) ep.loc[anchor0 * 4 + nn] = f2bf(r);
+                    else ep.conf[anchor0 * ep.classes + (nn - ep.n_loc)] = f2bf(r);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient.  grid (col tiles, co tiles, splits).  Per step 64 pixels.
+constexpr int WG_LD = 288;                   // LDS row stride (bytes) of a [pixel][128 ch] tile: 256 + 32 pad
+
+__global__ __launch_bounds__(WG) void k_conv_wgrad(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ dy,
+                                                   float* __restrict__ slab_w, float* __restrict__ slab_b, ConvGeom g,
+                                                   int m_per_split) {
+    // g: source = x dims (B,H,W,C), destination = dy dims (Ho,Wo,N); mul = stride, div = 1
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE = 64 * WG_LD;
+    auto s_dy = [&](int buf) { return smem + buf * (2 * TILE); };
+    auto s_x = [&](int buf) { return smem + buf * (2 * TILE) + TILE; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave & 1, wave_n = wave >> 1;       // m: co, n: (tap,ci) columns
+    const int col0 = blockIdx.x * 128, co0 = blockIdx.y * 128;
+    const int ktot = g.ldw;                                 // KH*KW*C columns
+    const int m_begin = blockIdx.z * m_per_split;
+    const int m_end = min(g.M, m_begin + m_per_split);
+
+    const int cslot = tid & 15, prow = tid >> 4;           // 16-byte column chunk, pixel row (+16j)
+    // this thread's X column chunk -> (tap, channel)
+    const int qx = (col0 >> 3) + cslot;
+    const bool xcol_ok = qx < g.nchunks;
+    const int tapx = xcol_ok ? qx / g.cpt : 0;
+    const int ccx = qx - tapx * g.cpt;
+    const int khx = tapx / g.KW, kwx = tapx - khx * g.KW;
+    const int co_chunk = co0 + cslot * 8;
+    const bool dycol_ok = co_chunk < g.N;
+
+    uint4 rdy[4], rxx[4];
+    auto load_tiles = [&](int mstep) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = mstep + prow + 16 * j;
+            const bool mok = m < m_end;
+            rdy[j] = make_uint4(0, 0, 0, 0);
+            rxx[j] = make_uint4(0, 0, 0, 0);
+            if (mok && dycol_ok) rdy[j] = *reinterpret_cast<const uint4*>(dy + ((long long)m * g.N + co_chunk));
+            if (mok && xcol_ok) {
+                const int b = fdiv(m, g.d_hw);
+                const int rem = m - b * g.d_hw.d;
+                const int oy = fdiv(rem, g.d_w);
+                const int ox = rem - oy * g.d_w.d;
+                const int iy = oy * g.mul - g.pad_t + khx, ix = ox * g.mul - g.pad_l + kwx;
+                if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
+                    rxx[j] = *reinterpret_cast<const uint4*>(x + ((((long long)b * g.H + iy) * g.W + ix) * g.C + ccx * 8));
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<uint4*>(s_dy(buf) + (prow + 16 * j) * WG_LD + cslot * 16) = rdy[j];
+            *reinterpret_cast<uint4*>(s_x(buf) + (prow + 16 * j) * WG_LD + cslot * 16) = rxx[j];
+        }
+    };
+
+    f32x4_t acc[4][4];
+    f32x4_t accb[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        accb[a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool do_bias = slab_b != nullptr && blockIdx.x == 0 && wave_n == 0;
+    bf16x8_t ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+
+    const int nsteps = (m_end - m_begin + 63) / 64;
+    if (nsteps > 0) {
+        load_tiles(m_begin);
+        store_tiles(0);
+    }
+    __syncthreads();
+    // transposing read: lane (16-group gq, index i) supplies the address of k-row (i>>2), columns 4*(i&3)..+3
+    const int gq = lane >> 4, li = lane & 15;
+    const int tr_row = li >> 2, tr_col = (li & 3) * 4;
+    for (int st = 0; st < nsteps; ++st) {
+        const int cur = st & 1;
+        const bool more = st + 1 < nsteps;
+        if (more) load_tiles(m_begin + (st + 1) * 64);
+#pragma unroll
+        for (int ksub = 0; ksub < 2; ++ksub) {
+            bf16x8_t fa[4], fb[4];
+            const int krow = ksub * 32 + gq * 8 + tr_row;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const char* base = s_dy(cur) + krow * WG_LD + (wave_m * 64 + a * 16 + tr_col) * 2;
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base));
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base + 4 * WG_LD));
+                union { s16x4_t h[2]; bf16x8_t v; } u;
+                u.h[0] = lo; u.h[1] = hi;
+                fa[a] = u.v;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const char* base = s_x(cur) + krow * WG_LD + (wave_n * 64 + c * 16 + tr_col) * 2;
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base));
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base + 4 * WG_LD));
+                union { s16x4_t h[2]; bf16x8_t v; } u;
+                u.h[0] = lo; u.h[1] = hi;
+                fb[c] = u.v;
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[c], acc[a][c], 0, 0, 0);
+            if (do_bias) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], ones, accb[a], 0, 0, 0);
+            }
+        }
+        if (more) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+    // partial tile -> slab[z][co][col]  (D[row = co (lane>>4)*4+j][col = lane&15])
+    float* out = slab_w + (long long)blockIdx.z * g.N * ktot;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int col = col0 + wave_n * 64 + c * 16 + (lane & 15);
+            if (col >= ktot) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = co0 + wave_m * 64 + a * 16 + (lane >> 4) * 4 + j;
+                if (co < g.N) out[(long long)co * ktot + col] = acc[a][c][j];
+            }
+        }
+    if (do_bias && (lane & 15) == 0) {
+        float* ob = slab_b + (long long)blockIdx.z * g.N;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = co0 + wave_m * 64 + a * 16 + (lane >> 4) * 4 + j;
+                if (co < g.N) ob[co] = accb[a][j];
+            }
+    }
+}
+
+// dW[i] = sum_z slab[z][i] in fixed order; also the bias gradient.
+__global__ void k_wgrad_reduce(const float* __restrict__ slab, long long n, int nsplit, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += slab[(long long)z * n + i];
+    out[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// W[co][kh][kw][ci] (bf16) -> Wt[ci][KH-1-kh][KW-1-kw][co] for the data gradient
+__global__ void k_weight_transpose(const bf16_raw* __restrict__ w, bf16_raw* __restrict__ wt, int Cout, int KH, int KW,
+                                   int Cin, int Cout_pad) {
+    // wt has row length KH*KW*Cout_pad (Cout padded to a multiple of 8 with zeros)
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)Cin * KH * KW * Cout_pad;
+    if (i >= total) return;
+    const int co = (int)(i % Cout_pad);
+    long long r = i / Cout_pad;
+    const int kw = (int)(r % KW); r /= KW;
+    const int kh = (int)(r % KH); r /= KH;
+    const int ci = (int)r;
+    bf16_raw v = 0;
+    if (co < Cout) v = w[(((long long)co * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)) * Cin + ci];
+    wt[i] = v;
+}
+
+// f32 -> bf16 cast (weights after an optimizer step)
+__global__ void k_cast_bf16(const float* __restrict__ src, bf16_raw* __restrict__ dst, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = f2bf(src[i]);
+}
+
+// image f32 [B,H,W,3] in [0,1] -> bf16 [B,H,W,8], (x-0.5)*2 (models/ssd_model.py:214), channels 3..7 zero
+__global__ void k_image_prep(const float* __restrict__ img, bf16_raw* __restrict__ out, long long npix, int normalize) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    float r = img[3 * i], gch = img[3 * i + 1], b = img[3 * i + 2];
+    if (normalize) { r = (r - 0.5f) * 2.f; gch = (gch - 0.5f) * 2.f; b = (b - 0.5f) * 2.f; }
+    *reinterpret_cast<uint4*>(out + 8 * i) =
+        make_uint4((unsigned)f2bf(r) | ((unsigned)f2bf(gch) << 16), (unsigned)f2bf(b), 0u, 0u);
+}
+
+// 2x2 stride-2 max pooling, NHWC bf16, 8 channels per thread.  pad_b/pad_r = 1 for TF "SAME" on odd sizes.
+__global__ void k_maxpool_fwd(const bf16_raw* __restrict__ x, bf16_raw* __restrict__ y, int B, int H, int W, int C,
+                              int Ho, int Wo) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c8 = C >> 3;
+    const long long total = (long long)B * Ho * Wo * c8;
+    if (i >= total) return;
+    const int c = (int)(i % c8);
+    long long r = i / c8;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    float best[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) best[k] = -INFINITY;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int iy = 2 * oy + dy, ix = 2 * ox + dx;
+            if (iy >= H || ix >= W) continue;
+            const uint4 v = *reinterpret_cast<const uint4*>(x + ((((long long)b * H + iy) * W + ix) * C + c * 8));
+            const unsigned wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                best[2 * k] = fmaxf(best[2 * k], __uint_as_float(wds[k] << 16));
+                best[2 * k + 1] = fmaxf(best[2 * k + 1], __uint_as_float(wds[k] & 0xffff0000u));
+            }
+        }
+    unsigned o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = (__float_as_uint(best[2 * k]) >> 16) | (__float_as_uint(best[2 * k + 1]) & 0xffff0000u);
+    *reinterpret_cast<uint4*>(y + ((((long long)b * Ho + oy) * Wo + ox) * C + c * 8)) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// Backward of the pooling + the ReLU in front of it: dx = dy at the first maximum of each window (TF
+// MaxPoolGrad), zero elsewhere and wherever x <= 0 (x is a post-ReLU activation).
+__global__ void k_maxpool_bwd(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ y, const bf16_raw* __restrict__ dy,
+                              bf16_raw* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c8 = C >> 3;
+    const long long total = (long long)B * Ho * Wo * c8;
+    if (i >= total) return;
+    const int c = (int)(i % c8);
+    long long r = i / c8;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    const long long oidx = (((long long)b * Ho + oy) * Wo + ox) * C + c * 8;
+    const uint4 yv = *reinterpret_cast<const uint4*>(y + oidx);
+    const uint4 gv = *reinterpret_cast<const uint4*>(dy + oidx);
+    const bf16_raw* yy = reinterpret_cast<const bf16_raw*>(&yv);
+    const bf16_raw* gg = reinterpret_cast<const bf16_raw*>(&gv);
+    bool done[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) done[k] = false;
+#pragma unroll
+    for (int dyy = 0; dyy < 2; ++dyy)
+#pragma unroll
+        for (int dxx = 0; dxx < 2; ++dxx) {
+            const int iy = 2 * oy + dyy, ix = 2 * ox + dxx;
+            if (iy >= H || ix >= W) continue;
+            const long long iidx = (((long long)b * H + iy) * W + ix) * C + c * 8;
+            const uint4 xv = *reinterpret_cast<const uint4*>(x + iidx);
+            const bf16_raw* xx = reinterpret_cast<const bf16_raw*>(&xv);
+            bf16_raw o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const bool hit = !done[k] && xx[k] == yy[k];
+                o[k] = (hit && bf2f(xx[k]) > 0.f) ? gg[k] : (bf16_raw)0;
+                done[k] = done[k] || hit;
+            }
+            *reinterpret_cast<uint4*>(dx + iidx) = *reinterpret_cast<const uint4*>(o);
+        }
+}
+
+// dloc [B][A][4], dconf [B][A][classes] (bf16) -> one level's padded NHWC gradient [B][H*W][npad]
+__global__ void k_head_grad_pack(const bf16_raw* __restrict__ dloc, const bf16_raw* __restrict__ dconf,
+                                 bf16_raw* __restrict__ out, int B, int hw, int per_cell, int classes, int npad,
+                                 int anchors_total, int level_off) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)B * hw * npad;
+    if (i >= total) return;
+    const int n = (int)(i % npad);
+    const long long r = i / npad;
+    const int pix = (int)(r % hw);
+    const int b = (int)(r / hw);
+    const int n_loc = per_cell * 4, n_conf = per_cell * classes;
+    const long long anchor0 = (long long)b * anchors_total + level_off + (long long)pix * per_cell;
+    bf16_raw v = 0;
+    if (n < n_loc) v = dloc[anchor0 * 4 + n];
+    else if (n < n_loc + n_conf) v = dconf[anchor0 * classes + (n - n_loc)];
+    out[i] = v;
+}
+
+ConvGeom make_geom(int B, int H, int W, int C, int Ho, int Wo, int N, int KH, int KW, int mul, int div, int pad_t,
+                   int pad_l) {
+    ConvGeom g;
+    g.B = B; g.H = H; g.W = W; g.C = C; g.Ho = Ho; g.Wo = Wo; g.N = N; g.KH = KH; g.KW = KW;
+    g.mul = mul; g.div = div; g.pad_t = pad_t; g.pad_l = pad_l;
+    g.M = B * Ho * Wo;
+    g.nchunks = KH * KW * C / 8;
+    g.ldw = KH * KW * C;
+    g.cpt = C / 8;
+    g.d_hw = make_fastdiv(Ho * Wo);
+    g.d_w = make_fastdiv(Wo);
+    return g;
+}
+
+template <int EPI>
+int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue& ep, hipStream_t s) {
+    const bf16_raw* xp = static_cast<const bf16_raw*>(x);
+    const bf16_raw* wp = static_cast<const bf16_raw*>(w);
+    const unsigned gm = (unsigned)((g.M + 127) / 128);
+    if (g.N <= 64) {
+        const size_t lds = 2 * (128 + 64) * 128;
+        hipLaunchKernelGGL((k_conv_igemm<64, EPI>), dim3(gm, (unsigned)((g.N + 63) / 64)), dim3(WG), lds, s, xp, wp, g, ep);
+    } else {
+        const size_t lds = 2 * (128 + 128) * 128;
+        hipLaunchKernelGGL((k_conv_igemm<128, EPI>), dim3(gm, (unsigned)((g.N + 127) / 128)), dim3(WG), lds, s, xp, wp, g, ep);
+    }
+    return ssd_launch_status();
+}
+
+bool geom_ok(int B, int H, int W, int C, int Ho, int Wo, int N, int K) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || N <= 0 || K <= 0) return false;
+    if (C % 8) return false;
+    if ((long long)B * Ho * Wo >= (1ll << 31) || (long long)B * H * W >= (1ll << 31)) return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssd_conv2d_fwd(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
+                   int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int relu, void* stream) {
+    if (!x || !w || !y || !geom_ok(B, H, W, Cin, Ho, Wo, Cout, ksize) || stride <= 0) return SSD_ERR_VALUE;
+    const ConvGeom g = make_geom(B, H, W, Cin, Ho, Wo, Cout, ksize, ksize, stride, 1, pad_t, pad_l);
+    Epilogue ep = {};
+    ep.bias = bias; ep.relu = relu; ep.out = static_cast<bf16_raw*>(y); ep.ldo = Cout;
+    return launch_igemm<EPI_FWD>(x, w, g, ep, (hipStream_t)stream);
+}
+
+int ssd_conv2d_head_fwd(const void* x, const void* w, const float* bias, void* loc, void* conf, int B, int H, int W,
+                        int Cin, int per_cell, int classes, int anchors_total, int level_off, void* stream) {
+    const int N = per_cell * (4 + classes);
+    if (!x || !w || !loc || !conf || !geom_ok(B, H, W, Cin, H, W, N, 3) || per_cell <= 0 || classes <= 0) return SSD_ERR_VALUE;
+    const ConvGeom g = make_geom(B, H, W, Cin, H, W, N, 3, 3, 1, 1, 1, 1);   // 3x3 SAME stride 1 (models/ssd_model.py:155-162)
+    Epilogue ep = {};
+    ep.bias = bias; ep.loc = static_cast<bf16_raw*>(loc); ep.conf = static_cast<bf16_raw*>(conf);
+    ep.n_loc = per_cell * 4; ep.n_conf = per_cell * classes; ep.anchors_total = anchors_total;
+    ep.level_off = level_off; ep.per_cell = per_cell; ep.classes = classes;
+    return launch_igemm<EPI_HEAD>(x, w, g, ep, (hipStream_t)stream);
+}
+
+int ssd_conv2d_bwd_data(const void* dy, const void* w_t, const void* relu_src, void* dx, int B, int H, int W, int Cin,
+                        int Cout_pad, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int accumulate,
+                        void* stream) {
+    // dy: [B,Ho,Wo,Cout_pad]; w_t: [Cin][k][k][Cout_pad] (ssd_weight_transpose); dx, relu_src: [B,H,W,Cin]
+    if (!dy || !w_t || !dx || !geom_ok(B, Ho, Wo, Cout_pad, H, W, Cin, ksize) || stride <= 0) return SSD_ERR_VALUE;
+    const ConvGeom g = make_geom(B, Ho, Wo, Cout_pad, H, W, Cin, ksize, ksize, 1, stride, ksize - 1 - pad_t,
+                                 ksize - 1 - pad_l);
+    Epilogue ep = {};
+    ep.out = static_cast<bf16_raw*>(dx); ep.ldo = Cin; ep.mask_src = static_cast<const bf16_raw*>(relu_src);
+    ep.accumulate = accumulate;
+    return launch_igemm<EPI_DGRAD>(dy, w_t, g, ep, (hipStream_t)stream);
+}
+
+static int wgrad_splits(long long M, int tiles) {
+    long long want = (1024 + tiles - 1) / tiles;            // ~4 workgroups per CU in total
+    long long maxs = (M + 255) / 256;                        // at least 256 pixels per split
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    if (want > 512) want = 512;
+    return (int)want;
+}
+
+size_t ssd_conv2d_bwd_weight_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ldy, int ksize) {
+    if (B <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || ldy < Cout || ksize <= 0) return 0;
+    const long long ktot = (long long)ksize * ksize * Cin;
+    const int tiles = (int)(((ktot + 127) / 128) * ((Cout + 127) / 128));
+    const int ns = wgrad_splits((long long)B * Ho * Wo, tiles);
+    return (size_t)ns * ((size_t)ldy * ktot + ldy) * sizeof(float);
+}
+
+int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias, int B, int H, int W, int Cin, int Cout,
+                          int ldy, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, void* ws, size_t ws_bytes,
+                          void* stream) {
+    // x: [B,H,W,Cin]; dy: [B,Ho,Wo,ldy] (first Cout channels used); dw: f32 [Cout][k][k][Cin]; dbias: f32 [Cout] or null
+    if (!x || !dy || !dw || !geom_ok(B, H, W, Cin, Ho, Wo, Cout, ksize) || stride <= 0 || ldy < Cout || ldy % 8) return SSD_ERR_VALUE;
+    if (!ws || ws_bytes < ssd_conv2d_bwd_weight_workspace_bytes(B, Ho, Wo, Cin, Cout, ldy, ksize)) return SSD_ERR_WORKSPACE;
+    ConvGeom g = make_geom(B, H, W, Cin, Ho, Wo, ldy, ksize, ksize, stride, 1, pad_t, pad_l);
+    const long long ktot = g.ldw;
+    const int ctiles = (int)((ktot + 127) / 128), mtiles = (Cout + 127) / 128;
+    const int ns = wgrad_splits(g.M, ctiles * mtiles);
+    int mps = (int)(((long long)g.M + ns - 1) / ns);
+    mps = (mps + 63) / 64 * 64;
+    float* slab_w = static_cast<float*>(ws);
+    float* slab_b = slab_w + (size_t)ns * ldy * ktot;
+    // the kernel indexes dy rows with g.N = ldy and guards co < g.N; slabs are laid out with ldy rows too
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = 4 * 64 * WG_LD;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) return SSD_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_conv_wgrad, dim3(ctiles, mtiles, ns), dim3(WG), lds, s, static_cast<const bf16_raw*>(x),
+                       static_cast<const bf16_raw*>(dy), slab_w, dbias ? slab_b : nullptr, g, mps);
+    if (hipGetLastError() != hipSuccess) return SSD_ERR_LAUNCH;
+    const long long nw = (long long)Cout * ktot;             // rows >= Cout of the slab are padding channels
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, slab_w, (long long)ldy * ktot,
+                       ns, dw);
+    if (dbias) hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((Cout + 255) / 256)), dim3(256), 0, s, slab_b,
+                                  (long long)ldy, ns, dbias);
+    return ssd_launch_status();
+}
+
+int ssd_weight_transpose(const void* w, void* w_t, int Cout, int ksize, int Cin, int Cout_pad, void* stream) {
+    if (!w || !w_t || Cout <= 0 || ksize <= 0 || Cin <= 0 || Cout_pad < Cout || Cout_pad % 8) return SSD_ERR_VALUE;
+    const long long total = (long long)Cin * ksize * ksize * Cout_pad;
+    hipLaunchKernelGGL(k_weight_transpose, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const bf16_raw*>(w), static_cast<bf16_raw*>(w_t), Cout, ksize, ksize, Cin, Cout_pad);
+    return ssd_launch_status();
+}
+
+int ssd_cast_bf16(const float* src, void* dst, long long n, void* stream) {
+    if (n < 0 || (n > 0 && (!src || !dst))) return SSD_ERR_VALUE;
+    if (n == 0) return SSD_OK;
+    hipLaunchKernelGGL(k_cast_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       static_cast<bf16_raw*>(dst), n);
+    return ssd_launch_status();
+}
+
+int ssd_image_prep(const float* img, void* out, int B, int H, int W, int normalize, void* stream) {
+    if (!img || !out || B <= 0 || H <= 0 || W <= 0) return SSD_ERR_VALUE;
+    const long long npix = (long long)B * H * W;
+    hipLaunchKernelGGL(k_image_prep, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, img,
+                       static_cast<bf16_raw*>(out), npix, normalize);
+    return ssd_launch_status();
+}
+
+int ssd_maxpool2x2_fwd(const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, void* stream) {
+    if (!x || !y || B <= 0 || C <= 0 || C % 8) return SSD_ERR_VALUE;
+    if ((Ho != H / 2 && Ho != (H + 1) / 2) || (Wo != W / 2 && Wo != (W + 1) / 2) || Ho <= 0 || Wo <= 0) return SSD_ERR_VALUE;
+    const long long total = (long long)B * Ho * Wo * (C / 8);
+    hipLaunchKernelGGL(k_maxpool_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const bf16_raw*>(x), static_cast<bf16_raw*>(y), B, H, W, C, Ho, Wo);
+    return ssd_launch_status();
+}
+
+int ssd_maxpool2x2_bwd(const void* x, const void* y, const void* dy, void* dx, int B, int H, int W, int C, int Ho, int Wo,
+                       void* stream) {
+    if (!x || !y || !dy || !dx || B <= 0 || C % 8) return SSD_ERR_VALUE;
+    if (2 * Ho < H || 2 * Wo < W) {
+        // VALID pooling of an odd size leaves the last row/column without gradient: clear it first
+        if (hipMemsetAsync(dx, 0, (size_t)B * H * W * C * 2, (hipStream_t)stream) != hipSuccess) return SSD_ERR_LAUNCH;
+    }
+    const long long total = (long long)B * Ho * Wo * (C / 8);
+    hipLaunchKernelGGL(k_maxpool_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const bf16_raw*>(x), static_cast<const bf16_raw*>(y), static_cast<const bf16_raw*>(dy),
+                       static_cast<bf16_raw*>(dx), B, H, W, C, Ho, Wo);
+    return ssd_launch_status();
+}
+
+int ssd_head_grad_pack(const void* dloc, const void* dconf, void* out, int B, int hw, int per_cell, int classes, int npad,
+                       int anchors_total, int level_off, void* stream) {
+    if (!dloc || !dconf || !out || B <= 0 || hw <= 0 || npad < per_cell * (4 + classes) || npad % 8) return SSD_ERR_VALUE;
+    const long long total = (long long)B * hw * npad;
+    hipLaunchKernelGGL(k_head_grad_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const bf16_raw*>(dloc), static_cast<const bf16_raw*>(dconf), static_cast<bf16_raw*>(out),
+                       B, hw, per_cell, classes, npad, anchors_total, level_off);
+    return ssd_launch_status();
+}
+
+}  // extern "C"

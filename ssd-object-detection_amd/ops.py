@@ -212,3 +212,141 @@ def nms(score, cls, box, cand, iou_thresh=0.45, max_cand=400, want_count=False):
     _lib.check(L.ssd_nms(_ptr(score), _ptr(cls), _ptr(box), _ptr(cand), B, A, float(iou_thresh), int(max_cand),
                          _ptr(keep), _ptr(count), _stream()))
     return (keep, count) if want_count else keep
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution stack (NHWC bf16)
+# ------------------------------------------------------------------------------------------------
+_conv_ws = MatchWorkspace()
+
+
+def same_pad(n, k, s):
+    """TF 'SAME': out = ceil(n/s); pad_total = max((out-1)*s + k - n, 0); returns (out, pad_before)."""
+    out = -(-n // s)
+    total = max((out - 1) * s + k - n, 0)
+    return out, total // 2
+
+
+def valid_out(n, k, s):
+    return (n - k) // s + 1
+
+
+def _bf(t):
+    assert t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous(), (t.dtype, t.is_contiguous())
+    return t
+
+
+def image_prep(img, normalize=True):
+    """f32 [B,H,W,3] in [0,1] -> bf16 [B,H,W,8] with (x-0.5)*2 (models/ssd_model.py:214), zero-padded channels."""
+    L = _lib.lib()
+    _dev(img, torch.float32)
+    B, H, W, _ = img.shape
+    out = torch.empty((B, H, W, 8), dtype=torch.bfloat16, device=img.device)
+    _lib.check(L.ssd_image_prep(_ptr(img), _ptr(out), B, H, W, 1 if normalize else 0, _stream()))
+    return out
+
+
+def conv2d_fwd(x, w, bias, stride, pad_t, pad_l, Ho, Wo, relu, out=None):
+    L = _lib.lib()
+    _bf(x); _bf(w)
+    B, H, W, Cin = x.shape
+    Cout, k = w.shape[0], w.shape[1]
+    assert w.shape == (Cout, k, k, Cin)
+    if out is None:
+        out = torch.empty((B, Ho, Wo, Cout), dtype=torch.bfloat16, device=x.device)
+    _lib.check(L.ssd_conv2d_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), B, H, W, Cin, Cout, k, stride, pad_t, pad_l,
+                                Ho, Wo, 1 if relu else 0, _stream()))
+    return out
+
+
+def conv2d_head_fwd(x, w, bias, loc, conf, per_cell, classes, level_off):
+    L = _lib.lib()
+    _bf(x); _bf(w); _bf(loc); _bf(conf)
+    B, H, W, Cin = x.shape
+    A = loc.shape[1]
+    assert w.shape == (per_cell * (4 + classes), 3, 3, Cin)
+    _lib.check(L.ssd_conv2d_head_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(loc), _ptr(conf), B, H, W, Cin, per_cell,
+                                     classes, A, level_off, _stream()))
+
+
+def weight_transpose(w, cout_pad=None, out=None):
+    L = _lib.lib()
+    _bf(w)
+    Cout, k, _, Cin = w.shape
+    cout_pad = cout_pad or (Cout + 7) // 8 * 8
+    if out is None:
+        out = torch.empty((Cin, k, k, cout_pad), dtype=torch.bfloat16, device=w.device)
+    _lib.check(L.ssd_weight_transpose(_ptr(w), _ptr(out), Cout, k, Cin, cout_pad, _stream()))
+    return out
+
+
+def conv2d_bwd_data(dy, w_t, relu_src, x_shape, stride, pad_t, pad_l, accumulate=False, out=None):
+    L = _lib.lib()
+    _bf(dy); _bf(w_t)
+    B, H, W, Cin = x_shape
+    _, Ho, Wo, cpad = dy.shape
+    k = w_t.shape[1]
+    assert w_t.shape == (Cin, k, k, cpad)
+    if out is None:
+        assert not accumulate
+        out = torch.empty(x_shape, dtype=torch.bfloat16, device=dy.device)
+    _lib.check(L.ssd_conv2d_bwd_data(_ptr(dy), _ptr(w_t), _ptr(relu_src), _ptr(out), B, H, W, Cin, cpad, k, stride,
+                                     pad_t, pad_l, Ho, Wo, 1 if accumulate else 0, _stream()))
+    return out
+
+
+def conv2d_bwd_weight(x, dy, Cout, k, stride, pad_t, pad_l, dw=None, dbias=None, want_bias=True, ws=None):
+    L = _lib.lib()
+    _bf(x); _bf(dy)
+    B, H, W, Cin = x.shape
+    _, Ho, Wo, ldy = dy.shape
+    if dw is None:
+        dw = torch.empty((Cout, k, k, Cin), dtype=torch.float32, device=x.device)
+    if dbias is None and want_bias:
+        dbias = torch.empty((Cout,), dtype=torch.float32, device=x.device)
+    nbytes = L.ssd_conv2d_bwd_weight_workspace_bytes(B, Ho, Wo, Cin, Cout, ldy, k)
+    wbuf = (ws or _conv_ws).get(nbytes, x.device)
+    _lib.check(L.ssd_conv2d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(dbias), B, H, W, Cin, Cout, ldy, k, stride,
+                                       pad_t, pad_l, Ho, Wo, _ptr(wbuf), wbuf.numel(), _stream()))
+    return dw, dbias
+
+
+def maxpool2x2_fwd(x, same=False):
+    L = _lib.lib()
+    _bf(x)
+    B, H, W, C = x.shape
+    Ho, Wo = ((H + 1) // 2, (W + 1) // 2) if same else (H // 2, W // 2)
+    y = torch.empty((B, Ho, Wo, C), dtype=torch.bfloat16, device=x.device)
+    _lib.check(L.ssd_maxpool2x2_fwd(_ptr(x), _ptr(y), B, H, W, C, Ho, Wo, _stream()))
+    return y
+
+
+def maxpool2x2_bwd(x, y, dy, out=None):
+    L = _lib.lib()
+    _bf(x); _bf(y); _bf(dy)
+    B, H, W, C = x.shape
+    _, Ho, Wo, _ = y.shape
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(L.ssd_maxpool2x2_bwd(_ptr(x), _ptr(y), _ptr(dy), _ptr(out), B, H, W, C, Ho, Wo, _stream()))
+    return out
+
+
+def head_grad_pack(dloc, dconf, hw, per_cell, classes, npad, level_off, out=None):
+    L = _lib.lib()
+    _bf(dloc); _bf(dconf)
+    B, A, _ = dloc.shape
+    if out is None:
+        out = torch.empty((B, hw, npad), dtype=torch.bfloat16, device=dloc.device)
+    _lib.check(L.ssd_head_grad_pack(_ptr(dloc), _ptr(dconf), _ptr(out), B, hw, per_cell, classes, npad, A, level_off,
+                                    _stream()))
+    return out
+
+
+def cast_bf16(src, dst=None):
+    L = _lib.lib()
+    _dev(src, torch.float32)
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+    _lib.check(L.ssd_cast_bf16(_ptr(src), _ptr(dst), src.numel(), _stream()))
+    return dst

@@ -1,0 +1,169 @@
+"""GPU numerics: MFMA implicit-GEMM convolution forward / data-gradient / weight-gradient and pooling through
+the C ABI vs a plain PyTorch fp32 reference of the same op (torch CPU conv2d on the same bf16-rounded operands,
+TF-SAME padding made explicit).  Parity for the network is UNPINNED by the reference (TensorFlow absent):
+tolerances are bf16 output rounding (fwd, dgrad: 2^-8 relative) and fp32 accumulation order (wgrad: 1e-3)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+import torch.nn.functional as F                                     # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import ssd_object_detection_amd.ops as ops_
+    return ops_
+
+
+def ref_conv(x, w, bias, k, stride, pad_t, pad_l, Ho, Wo, relu):
+    """x [B,H,W,C] f32, w [Cout,k,k,Cin] f32 -> [B,Ho,Wo,Cout] f32 with explicit (possibly asymmetric) padding."""
+    B, H, W, C = x.shape
+    pad_b = max((Ho - 1) * stride + k - H - pad_t, 0)
+    pad_r = max((Wo - 1) * stride + k - W - pad_l, 0)
+    xn = F.pad(x.permute(0, 3, 1, 2), (pad_l, pad_r, pad_t, pad_b))
+    y = F.conv2d(xn, w.permute(0, 3, 1, 2), bias, stride=stride)
+    assert y.shape[2] == Ho and y.shape[3] == Wo
+    if relu:
+        y = y.relu()
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+CASES = [
+    # B, H, W, Cin, Cout, k, stride, mode
+    (2, 38, 38, 64, 128, 3, 1, "same"),      # 3x3 SAME, BN=128 path
+    (2, 30, 30, 64, 64, 3, 1, "same"),       # BN=64 path
+    (3, 19, 19, 128, 256, 1, 1, "same"),     # 1x1
+    (2, 38, 38, 64, 96, 3, 2, "same"),       # stride 2, pad (0,1)  (38 -> 19)
+    (2, 19, 19, 64, 72, 3, 2, "same"),       # stride 2, pad (1,1)  (19 -> 10), N not a multiple of 16
+    (4, 5, 5, 128, 256, 3, 1, "valid"),      # 3x3 VALID (5 -> 3)
+    (5, 3, 3, 128, 256, 3, 1, "valid"),      # 3 -> 1, M = 5
+    (2, 20, 20, 8, 64, 3, 1, "same"),        # Cin = 8 (the padded image layer): taps share a k-step
+]
+
+
+def geometry(ops, H, W, k, stride, mode):
+    if mode == "same":
+        Ho, pt = ops.same_pad(H, k, stride)
+        Wo, pl = ops.same_pad(W, k, stride)
+    else:
+        Ho, Wo, pt, pl = ops.valid_out(H, k, stride), ops.valid_out(W, k, stride), 0, 0
+    return Ho, Wo, pt, pl
+
+
+@pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
+def test_conv_fwd_bwd(ops, case):
+    B, H, W, Cin, Cout, k, stride, mode = case
+    Ho, Wo, pt, pl = geometry(ops, H, W, k, stride, mode)
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn((B, H, W, Cin), generator=g).bfloat16()
+    w = (torch.randn((Cout, k, k, Cin), generator=g) / np.sqrt(k * k * Cin)).bfloat16()
+    bias = torch.randn((Cout,), generator=g) * 0.1
+    dy = torch.randn((B, Ho, Wo, Cout), generator=g).bfloat16()
+    xd, wd, bd, dyd = x.cuda(), w.cuda(), bias.cuda(), dy.cuda()
+
+    # forward (with and without ReLU)
+    for relu in (True, False):
+        y = ops.conv2d_fwd(xd, wd, bd, stride, pt, pl, Ho, Wo, relu).float().cpu()
+        yr = ref_conv(x.float(), w.float(), bias, k, stride, pt, pl, Ho, Wo, relu)
+        err = (y - yr).abs().max().item()
+        assert err <= 2 ** -7 * max(1.0, yr.abs().max().item()), ("fwd", relu, err)
+
+    # reference gradients by autograd (fp32)
+    xr = x.float().requires_grad_(True)
+    wr = w.float().requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    yr = ref_conv(xr, wr, br, k, stride, pt, pl, Ho, Wo, False)
+    yr.backward(dy.float())
+
+    # data gradient (no mask, then with a ReLU mask and accumulation)
+    w_t = ops.weight_transpose(wd)
+    dx = ops.conv2d_bwd_data(dyd, w_t, None, (B, H, W, Cin), stride, pt, pl).float().cpu()
+    scale = max(1.0, xr.grad.abs().max().item())
+    assert (dx - xr.grad).abs().max().item() <= 2 ** -7 * scale, "dgrad"
+    mask_src = torch.randn((B, H, W, Cin), generator=g).bfloat16()
+    base = torch.randn((B, H, W, Cin), generator=g).bfloat16()
+    acc = base.clone().cuda()
+    ops.conv2d_bwd_data(dyd, w_t, mask_src.cuda(), (B, H, W, Cin), stride, pt, pl, accumulate=True, out=acc)
+    want = (xr.grad + base.float()) * (mask_src.float() > 0)
+    assert (acc.float().cpu() - want).abs().max().item() <= 2 ** -6 * max(1.0, want.abs().max().item()), "dgrad+mask+acc"
+
+    # weight / bias gradient
+    dw, db = ops.conv2d_bwd_weight(xd, dyd, Cout, k, stride, pt, pl)
+    ws = max(1.0, wr.grad.abs().max().item())
+    assert (dw.cpu() - wr.grad).abs().max().item() <= 1e-3 * ws, "wgrad"
+    assert (db.cpu() - br.grad).abs().max().item() <= 1e-3 * max(1.0, br.grad.abs().max().item()), "bias grad"
+    # deterministic
+    dw2, _ = ops.conv2d_bwd_weight(xd, dyd, Cout, k, stride, pt, pl)
+    assert torch.equal(dw, dw2)
+
+
+def test_wgrad_padded_dy(ops):
+    """Head gradients arrive in a channel-padded tensor (ldy > Cout)."""
+    B, H, W, Cin, Cout, ldy = 2, 10, 10, 64, 340, 384
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((B, H, W, Cin), generator=g).bfloat16()
+    dy = torch.zeros((B, H, W, ldy)).bfloat16()
+    dy[..., :Cout] = torch.randn((B, H, W, Cout), generator=g).bfloat16()
+    w = torch.zeros((Cout, 3, 3, Cin), requires_grad=True)
+    yr = ref_conv(x.float(), w, None, 3, 1, 1, 1, H, W, False)
+    yr.backward(dy[..., :Cout].float())
+    dw, db = ops.conv2d_bwd_weight(x.cuda(), dy.cuda(), Cout, 3, 1, 1, 1)
+    assert (dw.cpu() - w.grad).abs().max().item() <= 1e-3 * w.grad.abs().max().item()
+    assert (db.cpu() - dy[..., :Cout].float().sum((0, 1, 2))).abs().max().item() <= 1e-3 * 30
+
+
+def test_head_fwd_layout(ops):
+    """Fused loc+conf head writes the reference's Reshape/Concatenate layout (models/ssd_model.py:166-167)."""
+    B, H, W, Cin, n, C = 2, 5, 5, 64, 6, 81
+    A, off = 200 + H * W * n, 200
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn((B, H, W, Cin), generator=g).bfloat16()
+    w = (torch.randn((n * (4 + C), 3, 3, Cin), generator=g) / 24).bfloat16()
+    bias = torch.randn((n * (4 + C),), generator=g) * 0.1
+    loc = torch.zeros((B, A, 4), dtype=torch.bfloat16, device="cuda")
+    conf = torch.zeros((B, A, C), dtype=torch.bfloat16, device="cuda")
+    ops.conv2d_head_fwd(x.cuda(), w.cuda(), bias.cuda(), loc, conf, n, C, off)
+    yr = ref_conv(x.float(), w.float(), bias, 3, 1, 1, 1, H, W, False)          # [B,H,W,n*85]
+    loc_r = yr[..., :n * 4].reshape(B, H * W * n, 4)
+    conf_r = yr[..., n * 4:].reshape(B, H * W * n, C)
+    assert (loc[:, off:].float().cpu() - loc_r).abs().max().item() <= 2 ** -7 * max(1, loc_r.abs().max().item())
+    assert (conf[:, off:].float().cpu() - conf_r).abs().max().item() <= 2 ** -7 * max(1, conf_r.abs().max().item())
+    assert float(loc[:, :off].abs().max()) == 0 and float(conf[:, :off].abs().max()) == 0
+    # and the inverse packing of the gradients
+    dloc = torch.randn((B, A, 4), generator=g).bfloat16().cuda()
+    dconf = torch.randn((B, A, C), generator=g).bfloat16().cuda()
+    npad = 512
+    packed = ops.head_grad_pack(dloc, dconf, H * W, n, C, npad, off).cpu()
+    want = torch.cat([dloc[:, off:].cpu().reshape(B, H * W, n * 4), dconf[:, off:].cpu().reshape(B, H * W, n * C)], -1)
+    assert torch.equal(packed[..., :n * 85], want) and float(packed[..., n * 85:].float().abs().max()) == 0
+
+
+@pytest.mark.parametrize("H,same", [(20, False), (75, True), (38, False)])
+def test_maxpool(ops, H, same):
+    B, C = 2, 64
+    g = torch.Generator().manual_seed(H)
+    x = torch.randn((B, H, H, C), generator=g).relu().bfloat16()        # post-ReLU activations (many exact zeros)
+    y = ops.maxpool2x2_fwd(x.cuda(), same=same)
+    xn = x.float().permute(0, 3, 1, 2)
+    if same and H % 2:
+        xn = F.pad(xn, (0, 1, 0, 1), value=float("-inf"))
+    yr = F.max_pool2d(xn, 2, 2).permute(0, 2, 3, 1)
+    assert torch.equal(y.float().cpu(), yr)
+    dy = torch.randn(y.shape, generator=g).bfloat16()
+    dx = ops.maxpool2x2_bwd(x.cuda(), y, dy.cuda()).float().cpu()
+    # reference: route to the first maximum of each window, then the ReLU mask x > 0
+    xr = x.float().requires_grad_(True)
+    xrn = xr.permute(0, 3, 1, 2)
+    if same and H % 2:
+        xrn = F.pad(xrn, (0, 1, 0, 1), value=float("-inf"))
+    F.max_pool2d(xrn, 2, 2).backward(dy.float().permute(0, 3, 1, 2))
+    want = xr.grad * (x.float() > 0)
+    assert torch.equal(dx * (x.float() > 0), dx)
+    assert (dx - want).abs().max().item() == 0
+
+
+def test_image_prep(ops):
+    img = torch.rand((2, 30, 30, 3))
+    out = ops.image_prep(img.cuda()).float().cpu()
+    assert torch.equal(out[..., :3], ((img - 0.5) * 2).bfloat16().float()) and float(out[..., 3:].abs().max()) == 0

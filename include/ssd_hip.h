@@ -193,6 +193,31 @@ int ssd_maxpool2x2_bwd(const void* x, const void* y, const void* dy, void* dx, i
 int ssd_head_grad_pack(const void* dloc, const void* dconf, void* out, int B, int hw, int per_cell, int classes,
                        int npad, int anchors_total, int level_off, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Optimizer step over one flat fp32 parameter buffer -- replaces the per-tensor Python loop of
+ * _train_step: tf.clip_by_norm(g, 0.01) (models/ssd_model.py:249), the micro-batch mean (:251-256) and
+ * optimizer.apply_gradients (:258-260; Adam/SGD and their hyper-parameters: tools/train.py:42-53).
+ * Every tensor starts on a multiple of ssd_opt_block_elems() elements (pad with zeros);
+ *   tensor_block_off int32[ntensors+1]: first block of each tensor;  block_tensor int32[n/block]: owner.
+ * ---------------------------------------------------------------------------------------- */
+int ssd_opt_block_elems(void);
+/* scale[t] = clip / max(||grad_t||_2, clip) (clip <= 0: 1), norms[t] optional; partial: double[n/block] scratch */
+int ssd_grad_clip_scales(const float* grad, long long n, const int32_t* tensor_block_off, int ntensors, float clip,
+                         double* partial, float* scale, float* norms, void* stream);
+/* grad *= scale[tensor]  in place (clipped gradients are what data-parallel ranks all-reduce) */
+int ssd_grad_apply_scale(float* grad, long long n, const int32_t* block_tensor, const float* scale, void* stream);
+/* acc = (first ? 0 : acc) + grad * scale[tensor]: the micro-batch accumulation of clipped gradients (:251-255) */
+int ssd_grad_accumulate(float* acc, const float* grad, long long n, const int32_t* block_tensor, const float* scale,
+                        int first, void* stream);
+/* Keras Adam with lr_t = lr*sqrt(1-b2^t)/(1-b1^t) precomputed by the caller; the gradient is multiplied by
+ * grad_scale (1/micro-batches or 1/world) and, if scale != NULL, by scale[tensor].  param_bf16 (may be NULL)
+ * receives the bf16 copy the convolutions read. */
+int ssd_adam_step(float* param, const float* grad, float* m, float* v, void* param_bf16, long long n,
+                  const int32_t* block_tensor, const float* scale, float grad_scale, float lr_t, float beta1,
+                  float beta2, float eps, void* stream);
+int ssd_sgd_step(float* param, const float* grad, void* param_bf16, long long n, const int32_t* block_tensor,
+                 const float* scale, float grad_scale, float lr, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,12 @@ _SIGNATURES = {
     "ssd_maxpool2x2_fwd": (ctypes.c_int, [VP, VP] + [ctypes.c_int] * 6 + [VP]),
     "ssd_maxpool2x2_bwd": (ctypes.c_int, [VP, VP, VP, VP] + [ctypes.c_int] * 6 + [VP]),
     "ssd_head_grad_pack": (ctypes.c_int, [VP, VP, VP] + [ctypes.c_int] * 7 + [VP]),
+    "ssd_opt_block_elems": (ctypes.c_int, []),
+    "ssd_grad_clip_scales": (ctypes.c_int, [VP, ctypes.c_longlong, VP, ctypes.c_int, ctypes.c_float, VP, VP, VP, VP]),
+    "ssd_grad_apply_scale": (ctypes.c_int, [VP, ctypes.c_longlong, VP, VP, VP]),
+    "ssd_grad_accumulate": (ctypes.c_int, [VP, VP, ctypes.c_longlong, VP, VP, ctypes.c_int, VP]),
+    "ssd_adam_step": (ctypes.c_int, [VP, VP, VP, VP, VP, ctypes.c_longlong, VP, VP] + [ctypes.c_float] * 5 + [VP]),
+    "ssd_sgd_step": (ctypes.c_int, [VP, VP, VP, ctypes.c_longlong, VP, VP, ctypes.c_float, ctypes.c_float, VP]),
     "ssd_loss_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "ssd_loss_fwd_bwd": (ctypes.c_int, [VP, VP, ctypes.c_int, VP, VP, VP, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_float, VP, VP, VP, VP, ctypes.c_size_t, VP]),

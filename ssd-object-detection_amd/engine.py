@@ -1,0 +1,311 @@
+"""Execution engine of the SSD300 network on the gfx950 library: parameter storage, forward, backward and
+the optimizer step.  Python only sequences C-ABI calls (ops.py / _lib.py); every tensor operation runs in
+libssd_hip.so.  torch provides device memory, streams and (for data parallelism) torch.distributed.
+
+Network = SSDObjectDetectionModel._build of the reference (models/ssd_model.py:74-171): Keras VGG16 up to
+block3_conv3, a SAME max-pool, three 38x38 convolutions, five extra stages, and per-level 3x3 loc/conf heads.
+Activations are NHWC bf16, weights [Cout][k][k][Cin] bf16 (fp32 masters), accumulation fp32 on MFMA.
+The 3-channel image is carried in 8 zero-padded channels (first-layer weights of channels 3..7 are and stay 0).
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+# (kind, cin, cout, k, stride, mode, feature_map)   -- mode: TF padding; every conv has ReLU
+SSD300_TRUNK = [
+    ("conv", 8, 64, 3, 1, "same", False),        # block1_conv1   (Cin 3 padded to 8)
+    ("conv", 64, 64, 3, 1, "same", False),       # block1_conv2
+    ("pool", 64, 64, 2, 2, "valid", False),      # block1_pool 300 -> 150
+    ("conv", 64, 128, 3, 1, "same", False),      # block2_conv1
+    ("conv", 128, 128, 3, 1, "same", False),     # block2_conv2
+    ("pool", 128, 128, 2, 2, "valid", False),    # block2_pool 150 -> 75
+    ("conv", 128, 256, 3, 1, "same", False),     # block3_conv1
+    ("conv", 256, 256, 3, 1, "same", False),     # block3_conv2
+    ("conv", 256, 256, 3, 1, "same", False),     # block3_conv3                     models/ssd_model.py:77-82
+    ("pool", 256, 256, 2, 2, "same", False),     # MaxPool2D SAME 75 -> 38           :84
+    ("conv", 256, 512, 3, 1, "same", False),     # :86
+    ("conv", 512, 512, 3, 1, "same", False),     # :90
+    ("conv", 512, 512, 1, 1, "same", True),      # :94   -> feature map 0 (38x38x512)
+    ("conv", 512, 1024, 3, 2, "same", False),    # :102
+    ("conv", 1024, 1024, 1, 1, "same", True),    # :107  -> feature map 1 (19x19x1024)
+    ("conv", 1024, 256, 1, 1, "same", False),    # :113
+    ("conv", 256, 512, 3, 2, "same", True),      # :117  -> feature map 2 (10x10x512)
+    ("conv", 512, 128, 1, 1, "same", False),     # :124
+    ("conv", 128, 256, 3, 2, "same", True),      # :128  -> feature map 3 (5x5x256)
+    ("conv", 256, 128, 1, 1, "same", False),     # :135
+    ("conv", 128, 256, 3, 1, "valid", True),     # :139  -> feature map 4 (3x3x256)
+    ("conv", 256, 128, 1, 1, "same", False),     # :144
+    ("conv", 128, 256, 3, 1, "valid", True),     # :148  -> feature map 5 (1x1x256)
+]
+SSD300_NUM_PRIORS = (4, 6, 6, 6, 4, 4)           # models/ssd_model.py:153
+IMAGE_CHANNELS = 3
+
+
+class ParamTensor:
+    def __init__(self, name, shape, offset):
+        self.name, self.shape, self.offset = name, tuple(shape), offset
+        self.numel = int(np.prod(shape))
+
+
+class SSDEngine:
+    def __init__(self, classes=81, in_size=300, trunk=SSD300_TRUNK, num_priors=SSD300_NUM_PRIORS, device="cuda",
+                 seed=0):
+        self.L = _lib.lib()
+        self.classes, self.in_size, self.device = classes, in_size, torch.device(device)
+        self.trunk, self.num_priors = list(trunk), tuple(num_priors)
+        self.block = self.L.ssd_opt_block_elems()
+        self._plan_shapes()
+        self._plan_params()
+        self._alloc_params()
+        self.init_params(seed)
+        self._act_cache = {}
+        self._ws = ops.MatchWorkspace()
+        self.step_count = 0
+
+    # ---------------------------------------------------------------- static planning
+    def _plan_shapes(self):
+        s = self.in_size
+        self.nodes = []                       # dicts: kind, cin, cout, k, stride, pt, pl, hin, hout, feature
+        self.fm = []                          # (node index, h, c)
+        for kind, cin, cout, k, stride, mode, feat in self.trunk:
+            if mode == "same":
+                ho, pt = ops.same_pad(s, k, stride)
+            else:
+                ho, pt = ops.valid_out(s, k, stride), 0
+            self.nodes.append(dict(kind=kind, cin=cin, cout=cout, k=k, stride=stride, pt=pt, pl=pt, hin=s, hout=ho,
+                                   feature=feat, same=(mode == "same")))
+            s = ho
+            if feat:
+                self.fm.append((len(self.nodes) - 1, ho, cout))
+        assert len(self.fm) == len(self.num_priors)
+        self.level_off = [0]
+        for (_, h, _), n in zip(self.fm, self.num_priors):
+            self.level_off.append(self.level_off[-1] + h * h * n)
+        self.A = self.level_off[-1]            # 8732 for SSD300 (models/ssd_model.py:221)
+        self.grids = tuple((h, h) for _, h, _ in self.fm)
+
+    def _plan_params(self):
+        self.tensors = []
+        off = 0
+
+        def add(name, shape):
+            nonlocal off
+            t = ParamTensor(name, shape, off)
+            self.tensors.append(t)
+            off += (t.numel + self.block - 1) // self.block * self.block
+            return t
+
+        self.conv_params = {}
+        for i, nd in enumerate(self.nodes):
+            if nd["kind"] != "conv":
+                continue
+            self.conv_params[i] = (add("conv%d/kernel" % i, (nd["cout"], nd["k"], nd["k"], nd["cin"])),
+                                   add("conv%d/bias" % i, (nd["cout"],)))
+        self.head_params = []
+        for lvl, ((_, h, c), n) in enumerate(zip(self.fm, self.num_priors)):
+            nout = n * (4 + self.classes)      # loc filters (n*4) then conf filters (n*classes): one fused GEMM
+            self.head_params.append((add("head%d/kernel" % lvl, (nout, 3, 3, c)), add("head%d/bias" % lvl, (nout,))))
+        self.n_flat = off
+        self.n_params = sum(t.numel for t in self.tensors)
+
+    def _alloc_params(self):
+        dev, n = self.device, self.n_flat
+        self.param = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grad_acc = None
+        self.adam_m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.adam_v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.param_bf16 = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+        nb = n // self.block
+        tbo = np.zeros(len(self.tensors) + 1, np.int32)
+        bt = np.zeros(nb, np.int32)
+        for i, t in enumerate(self.tensors):
+            b0 = t.offset // self.block
+            b1 = b0 + (t.numel + self.block - 1) // self.block
+            tbo[i], tbo[i + 1] = b0, b1
+            bt[b0:b1] = i
+        self.tensor_block_off = torch.from_numpy(tbo).to(dev)
+        self.block_tensor = torch.from_numpy(bt).to(dev)
+        self.sq_partial = torch.empty(nb, dtype=torch.float64, device=dev)
+        self.clip_scale = torch.empty(len(self.tensors), dtype=torch.float32, device=dev)
+        self.grad_norms = torch.empty(len(self.tensors), dtype=torch.float32, device=dev)
+        # transposed weights for the data gradient (own buffers)
+        self.w_t = {}
+        for i, nd in enumerate(self.nodes):
+            if nd["kind"] == "conv" and i > 0:
+                self.w_t[i] = torch.empty((nd["cin"], nd["k"], nd["k"], nd["cout"]), dtype=torch.bfloat16, device=dev)
+        self.head_npad = [(n * (4 + self.classes) + 7) // 8 * 8 for n in self.num_priors]
+        self.head_w_t = [torch.empty((c, 3, 3, npad), dtype=torch.bfloat16, device=dev)
+                         for (_, _, c), npad in zip(self.fm, self.head_npad)]
+
+    # ---------------------------------------------------------------- parameter views
+    def view(self, t, buf):
+        return buf[t.offset:t.offset + t.numel].view(t.shape)
+
+    def init_params(self, seed=0):
+        """Keras defaults: glorot_uniform kernels, zero biases (the reference's VGG part loads ImageNet weights
+        from the network, which is unavailable offline -- SURVEY.md F9)."""
+        rng = np.random.default_rng(seed)
+        host = np.zeros(self.n_flat, np.float32)
+        for t in self.tensors:
+            if not t.name.endswith("kernel"):
+                continue
+            cout, k, _, cin = t.shape
+            if t.name.startswith("head"):
+                lvl = int(t.name[4:t.name.index("/")])
+                n = self.num_priors[lvl]
+                parts = []
+                for rows in (n * 4, n * self.classes):          # two separate Keras layers (:155-162)
+                    lim = math.sqrt(6.0 / (k * k * cin + k * k * rows))
+                    parts.append(rng.uniform(-lim, lim, (rows, k, k, cin)))
+                w = np.concatenate(parts, 0)
+            else:
+                real_cin = IMAGE_CHANNELS if t.name == "conv0/kernel" else cin
+                lim = math.sqrt(6.0 / (k * k * real_cin + k * k * cout))
+                w = rng.uniform(-lim, lim, (cout, k, k, cin))
+                if real_cin != cin:
+                    w[..., real_cin:] = 0.0
+            host[t.offset:t.offset + t.numel] = w.astype(np.float32).reshape(-1)
+        self.param.copy_(torch.from_numpy(host))
+        self.adam_m.zero_()
+        self.adam_v.zero_()
+        self.step_count = 0
+        self.refresh_weights(cast=True)
+
+    def refresh_weights(self, cast=False):
+        """bf16 copy (if not already written by the optimizer kernel) + transposed copies for the data gradient."""
+        if cast:
+            ops.cast_bf16(self.param, self.param_bf16)
+        for i, wt in self.w_t.items():
+            ops.weight_transpose(self.view(self.conv_params[i][0], self.param_bf16), wt.shape[-1], out=wt)
+        for lvl, wt in enumerate(self.head_w_t):
+            ops.weight_transpose(self.view(self.head_params[lvl][0], self.param_bf16), wt.shape[-1], out=wt)
+
+    # ---------------------------------------------------------------- activations
+    def _acts(self, B):
+        c = self._act_cache.get(B)
+        if c is None:
+            dev = self.device
+            acts = [None]                         # acts[0] = network input, set per call
+            gacts = [None]
+            for nd in self.nodes:
+                shape = (B, nd["hout"], nd["hout"], nd["cout"])
+                acts.append(torch.empty(shape, dtype=torch.bfloat16, device=dev))
+                gacts.append(torch.empty(shape, dtype=torch.bfloat16, device=dev))
+            loc = torch.empty((B, self.A, 4), dtype=torch.bfloat16, device=dev)
+            conf = torch.empty((B, self.A, self.classes), dtype=torch.bfloat16, device=dev)
+            packed = [torch.empty((B, h * h, npad), dtype=torch.bfloat16, device=dev)
+                      for (_, h, _), npad in zip(self.fm, self.head_npad)]
+            c = dict(acts=acts, gacts=gacts, loc=loc, conf=conf, packed=packed)
+            self._act_cache = {B: c}              # keep one batch size resident
+        return c
+
+    # ---------------------------------------------------------------- forward / backward
+    def forward(self, x):
+        """x: bf16 [B, S, S, 8] (ops.image_prep).  Returns (loc bf16 [B,A,4], conf bf16 [B,A,classes])."""
+        B = x.shape[0]
+        c = self._acts(B)
+        acts = c["acts"]
+        acts[0] = x
+        for i, nd in enumerate(self.nodes):
+            if nd["kind"] == "conv":
+                wt, bt = self.conv_params[i]
+                ops.conv2d_fwd(acts[i], self.view(wt, self.param_bf16), self.view(bt, self.param), nd["stride"],
+                               nd["pt"], nd["pl"], nd["hout"], nd["hout"], True, out=acts[i + 1])
+            else:
+                L = self.L
+                _lib.check(L.ssd_maxpool2x2_fwd(ops._ptr(acts[i]), ops._ptr(acts[i + 1]), B, nd["hin"], nd["hin"],
+                                                nd["cin"], nd["hout"], nd["hout"], ops._stream()))
+        for lvl, (ni, h, ch) in enumerate(self.fm):
+            wt, bt = self.head_params[lvl]
+            ops.conv2d_head_fwd(acts[ni + 1], self.view(wt, self.param_bf16), self.view(bt, self.param), c["loc"],
+                                c["conf"], self.num_priors[lvl], self.classes, self.level_off[lvl])
+        return c["loc"], c["conf"]
+
+    def backward(self, dloc, dconf):
+        """Gradients of all parameters into self.grad (flat fp32) from d(loss)/d(loc), d(loss)/d(conf)."""
+        B = dloc.shape[0]
+        c = self._acts(B)
+        acts, gacts = c["acts"], c["gacts"]
+        written = [False] * len(acts)
+        # heads: weight gradients and their contribution to the feature-map gradients
+        for lvl, (ni, h, ch) in enumerate(self.fm):
+            n = self.num_priors[lvl]
+            packed = ops.head_grad_pack(dloc, dconf, h * h, n, self.classes, self.head_npad[lvl], self.level_off[lvl],
+                                        out=c["packed"][lvl]).view(B, h, h, self.head_npad[lvl])
+            wt, bt = self.head_params[lvl]
+            ops.conv2d_bwd_weight(acts[ni + 1], packed, wt.shape[0], 3, 1, 1, 1, dw=self.view(wt, self.grad),
+                                  dbias=self.view(bt, self.grad), ws=self._ws)
+            ops.conv2d_bwd_data(packed, self.head_w_t[lvl], acts[ni + 1], acts[ni + 1].shape, 1, 1, 1,
+                                accumulate=False, out=gacts[ni + 1])
+            written[ni + 1] = True
+        # trunk, last layer first
+        for i in range(len(self.nodes) - 1, -1, -1):
+            nd = self.nodes[i]
+            g_out = gacts[i + 1]
+            assert written[i + 1]
+            if nd["kind"] == "pool":
+                ops.maxpool2x2_bwd(acts[i], acts[i + 1], g_out, out=gacts[i])
+                written[i] = True
+                continue
+            wt, bt = self.conv_params[i]
+            ops.conv2d_bwd_weight(acts[i], g_out, nd["cout"], nd["k"], nd["stride"], nd["pt"], nd["pl"],
+                                  dw=self.view(wt, self.grad), dbias=self.view(bt, self.grad), ws=self._ws)
+            if i == 0:
+                continue                          # no gradient w.r.t. the image
+            prev_is_relu_conv = self.nodes[i - 1]["kind"] == "conv"
+            ops.conv2d_bwd_data(g_out, self.w_t[i], acts[i] if prev_is_relu_conv else None, acts[i].shape, nd["stride"],
+                                nd["pt"], nd["pl"], accumulate=written[i], out=gacts[i])
+            written[i] = True
+
+    # ---------------------------------------------------------------- optimizer
+    def clip_scales(self, clip=0.01):
+        """Per-tensor scale = clip / max(||g||, clip)  (tf.clip_by_norm, models/ssd_model.py:249)."""
+        _lib.check(self.L.ssd_grad_clip_scales(ops._ptr(self.grad), self.n_flat, ops._ptr(self.tensor_block_off),
+                                               len(self.tensors), float(clip), ops._ptr(self.sq_partial),
+                                               ops._ptr(self.clip_scale), ops._ptr(self.grad_norms), ops._stream()))
+
+    def apply_clip_in_place(self):
+        _lib.check(self.L.ssd_grad_apply_scale(ops._ptr(self.grad), self.n_flat, ops._ptr(self.block_tensor),
+                                               ops._ptr(self.clip_scale), ops._stream()))
+
+    def accumulate_clipped(self, first):
+        if self.grad_acc is None:
+            self.grad_acc = torch.empty_like(self.grad)
+        _lib.check(self.L.ssd_grad_accumulate(ops._ptr(self.grad_acc), ops._ptr(self.grad), self.n_flat,
+                                              ops._ptr(self.block_tensor), ops._ptr(self.clip_scale), 1 if first else 0,
+                                              ops._stream()))
+
+    def adam(self, lr, grad, grad_scale=1.0, use_clip_scale=False, beta1=0.9, beta2=0.999, eps=1e-7):
+        self.step_count += 1
+        t = self.step_count
+        lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+        _lib.check(self.L.ssd_adam_step(ops._ptr(self.param), ops._ptr(grad), ops._ptr(self.adam_m), ops._ptr(self.adam_v),
+                                        ops._ptr(self.param_bf16), self.n_flat, ops._ptr(self.block_tensor),
+                                        ops._ptr(self.clip_scale) if use_clip_scale else None, float(grad_scale),
+                                        float(lr_t), float(beta1), float(beta2), float(eps), ops._stream()))
+        self.refresh_weights()
+
+    def sgd(self, lr, grad, grad_scale=1.0, use_clip_scale=False):
+        self.step_count += 1
+        _lib.check(self.L.ssd_sgd_step(ops._ptr(self.param), ops._ptr(grad), ops._ptr(self.param_bf16), self.n_flat,
+                                       ops._ptr(self.block_tensor), ops._ptr(self.clip_scale) if use_clip_scale else None,
+                                       float(grad_scale), float(lr), ops._stream()))
+        self.refresh_weights()
+
+    # ---------------------------------------------------------------- state
+    def state_dict(self):
+        return dict(param=self.param.cpu(), adam_m=self.adam_m.cpu(), adam_v=self.adam_v.cpu(), step=self.step_count,
+                    names=[t.name for t in self.tensors], shapes=[t.shape for t in self.tensors],
+                    offsets=[t.offset for t in self.tensors])
+
+    def load_state_dict(self, sd):
+        self.param.copy_(sd["param"])
+        self.adam_m.copy_(sd["adam_m"])
+        self.adam_v.copy_(sd["adam_v"])
+        self.step_count = int(sd["step"])
+        self.refresh_weights(cast=True)

@@ -1,0 +1,3 @@
+from .ssd.make_dataset import SSDDataLoader
+
+__all__ = ["SSDDataLoader"]

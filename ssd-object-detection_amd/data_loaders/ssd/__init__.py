@@ -1,0 +1,3 @@
+from .make_dataset import SSDDataLoader
+
+__all__ = ["SSDDataLoader"]

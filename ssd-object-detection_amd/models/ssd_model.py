@@ -1,0 +1,227 @@
+"""SSDObjectDetectionModel with the reference's surface (models/ssd_model.py of the reference: constructor
+:50-52, TrainConfig :20-40, train :326, get_train_set :209, _train_step :229, _ssd_loss :341, get_prior_box
+:416, save/load :405-411, get_log_dir :419), executed on MI355X by the HIP engine.
+
+What differs from the reference, by design:
+  * get_train_set batches samples first and runs target assignment for the whole batch on the device.
+  * _ssd_loss / _train_step return device tensors; nothing synchronises the host unless the caller reads a
+    scalar (the reference forces >= 4 device->host copies per micro-batch, :389-394).
+  * `distributed=True` shards the batch by image over torch.distributed ranks: every rank is one micro-batch
+    (loss, mining and per-tensor clipping are per rank, as the reference does per micro-batch :240-256), the
+    clipped gradients are summed with one RCCL all-reduce and divided by the rank count.
+  * inference adds a real NMS pass (`detect`), which the reference lacks.
+"""
+import logging
+import os
+import time
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..engine import SSDEngine
+from .. import optimizers as _opt
+
+logger = logging.getLogger(__name__)
+
+
+class SSDObjectDetectionModel:
+    class TrainConfig:
+        def __init__(self, epoch, batch_size, optimizer, warmup=True, warmup_optimizer=None, warmup_step=1000,
+                     visualization_log_interval=10, split_batch=False, split_batch_size=4):
+            if warmup_optimizer is None:
+                warmup_optimizer = _opt.Adam(_opt.PolynomialDecay(1e-6, 1000, 0.001))
+            self.epoch = epoch
+            self.batch_size = batch_size
+            self.optimizer = optimizer
+            self.warmup = warmup
+            self.warmup_optimizer = warmup_optimizer
+            self.warmup_step = warmup_step
+            self.visualization_log_interval = visualization_log_interval
+            self.split_batch = split_batch
+            self.split_batch_size = split_batch_size
+
+    class Config:
+        def __init__(self, classes, log_dir):
+            self.log_dir = log_dir
+            self.input_shape = (300, 300, 3)
+            self.classes = classes + 1               # background is the LAST class index
+            self.thresh = 0.5
+
+    def __init__(self, classes, log_dir, device="cuda", seed=0, distributed=False, timestamp_dir=True):
+        if timestamp_dir:
+            log_dir = os.path.join(log_dir, time.strftime("%Y-%m-%d-%H%M%S", time.localtime()))
+        self.cfg = SSDObjectDetectionModel.Config(classes, log_dir)
+        self.device = torch.device(device)
+        self.distributed = bool(distributed)
+        self._engine = SSDEngine(classes=self.cfg.classes, in_size=self.cfg.input_shape[0], device=device, seed=seed)
+        self._pset = ops.build_priors(grids=self._engine.grids, device=device)
+        assert self._pset.A == self._engine.A
+        self._prior_box = None
+        self._comm_stream = None
+        self._slot_owner = None                      # optimizer object whose Adam moments the engine holds
+        self.last_info = None
+
+    # ------------------------------------------------------------------ accessors
+    def get_prior_box(self):
+        """float64 [8732, 4] numpy array, as the reference returns."""
+        if self._prior_box is None:
+            self._prior_box = self._pset.priors.cpu().numpy()
+        return self._prior_box
+
+    def get_log_dir(self):
+        return self.cfg.log_dir
+
+    def get_engine(self):
+        return self._engine
+
+    # ------------------------------------------------------------------ input pipeline (A8)
+    def get_train_set(self, dataset, batch_size=1):
+        """Iterable of (image f32[B,300,300,3] in [-1,1], (cls i32[B,A], loc f32[B,A,4], mask u8[B,A])) device
+        batches; remainder dropped (reference :209-227: match_bbox -> apply_anchor_box -> (x-0.5)*2 -> batch)."""
+        model = self
+
+        class _Batches:
+            def __iter__(self_inner):
+                imgs, clss, boxes = [], [], []
+                for image, cls, box in dataset:
+                    imgs.append(np.asarray(image, np.float32))
+                    clss.append(np.asarray(cls, np.float32))
+                    boxes.append(np.asarray(box, np.float32))
+                    if len(imgs) == batch_size:
+                        yield model.make_batch(imgs, clss, boxes)
+                        imgs, clss, boxes = [], [], []
+
+        return _Batches()
+
+    def make_batch(self, images, cls_list, box_list):
+        img = torch.from_numpy(np.stack(images, 0)).to(self.device, non_blocking=True)
+        img = (img - 0.5) * 2                          # reference :214 (exact in fp32)
+        gt = ops.pack_gt(box_list, cls_list, device=self.device)
+        cls, loc, mask = ops.match_encode(*gt, self._pset, self.cfg.thresh)
+        return img, (cls, loc, mask)
+
+    # ------------------------------------------------------------------ loss (A6)
+    @staticmethod
+    def _ssd_loss(y_true, y_pred):
+        """Returns (total loss tensor, info) where info maps the reference's three names to device scalars and
+        carries the gradients w.r.t. (pred_box, pred_cls) under 'dloc' / 'dconf'."""
+        gt_cls, gt_box, gt_mask = y_true
+        pred_box, pred_cls = y_pred
+        assert gt_cls.shape[0] == gt_box.shape[0] == gt_mask.shape[0] == pred_box.shape[0] == pred_cls.shape[0]
+        out, dconf, dloc = ops.ssd_loss(pred_cls, pred_box, gt_cls, gt_box, gt_mask)
+        info = {"cls loss pos": out[1], "cls loss neg": out[2], "loc loss": out[0], "status": out[7],
+                "dconf": dconf, "dloc": dloc, "raw": out}
+        return out[3], info
+
+    # ------------------------------------------------------------------ train step (A7)
+    def _train_step(self, image, gt_cls, gt_bbox, gt_mask, ssd_optimizer, stage="train", set_names=None,
+                    set_colors=None, step=0, cfg=None):
+        eng = self._engine
+        batch_size = image.shape[0]
+        batch_step = batch_size if (cfg is None or not cfg.split_batch) else cfg.split_batch_size
+        n_micro = 0
+        info = None
+        world = torch.distributed.get_world_size() if self.distributed else 1
+        single = world == 1 and batch_step >= batch_size
+        for i in range(0, batch_size, batch_step):
+            x = ops.image_prep(image[i:i + batch_step].contiguous(), normalize=False)
+            pred_loc, pred_conf = eng.forward(x)
+            _, info = self._ssd_loss((gt_cls[i:i + batch_step], gt_bbox[i:i + batch_step], gt_mask[i:i + batch_step]),
+                                     (pred_loc, pred_conf))
+            eng.backward(info["dloc"], info["dconf"])
+            eng.clip_scales(0.01)                      # tf.clip_by_norm(x, 0.01) per tensor, reference :249
+            if not single:
+                eng.accumulate_clipped(first=(n_micro == 0))
+            n_micro += 1
+        if self._slot_owner is not ssd_optimizer:     # Keras keeps separate slots per optimizer (warm-up vs train)
+            eng.adam_m.zero_()
+            eng.adam_v.zero_()
+            self._slot_owner = ssd_optimizer
+        lr = ssd_optimizer.lr()
+        if single:
+            grad, gscale, use_clip = eng.grad, 1.0, True
+        else:
+            grad, use_clip = eng.grad_acc, False
+            if world > 1:
+                torch.distributed.all_reduce(grad)     # RCCL over xGMI: sum of the ranks' clipped gradients
+            gscale = 1.0 / (n_micro * world)           # reference :256
+        if isinstance(ssd_optimizer, _opt.SGD):
+            eng.sgd(lr, grad, gscale, use_clip)
+        else:
+            eng.step_count = ssd_optimizer.iterations
+            eng.adam(lr, grad, gscale, use_clip, ssd_optimizer.beta_1, ssd_optimizer.beta_2, ssd_optimizer.epsilon)
+        ssd_optimizer.iterations += 1
+        info = {k: v for k, v in info.items() if k in ("cls loss pos", "cls loss neg", "loc loss", "status")}
+        info["lr"] = lr
+        self.last_info = info
+        return pred_conf, pred_loc, info
+
+    # ------------------------------------------------------------------ trainer shell
+    def _train(self, data_loader, cfg):
+        train_set, _val_set = data_loader.get_dataset()
+        set_names, set_colors = data_loader.get_names_and_colors()
+        batches = self.get_train_set(train_set, batch_size=cfg.batch_size)
+        if cfg.warmup:
+            logger.info("Warm up for %s steps", cfg.warmup_step)
+            step = 0
+            while step < cfg.warmup_step:
+                got = False
+                for image, (gt_cls, gt_bbox, gt_mask) in batches:
+                    got = True
+                    step += 1
+                    _, _, info = self._train_step(image, gt_cls, gt_bbox, gt_mask, cfg.warmup_optimizer, "warmup",
+                                                  set_names, set_colors, step, cfg)
+                    self._log(step, info, cfg, "warmup")
+                    if step >= cfg.warmup_step:
+                        break
+                if not got:
+                    break
+        step = 0
+        for epoch in range(cfg.epoch):
+            logger.info("Epoch %s/%s", epoch + 1, cfg.epoch)
+            for image, (gt_cls, gt_bbox, gt_mask) in batches:
+                step += 1
+                _, _, info = self._train_step(image, gt_cls, gt_bbox, gt_mask, cfg.optimizer, "train", set_names,
+                                              set_colors, step, cfg)
+                self._log(step, info, cfg, "train")
+            self.save(os.path.join(self.cfg.log_dir, "model_weight", "model_weight_epoch_%d.pt" % epoch))
+
+    def _log(self, step, info, cfg, stage):
+        if step % max(1, cfg.visualization_log_interval) == 0:
+            vals = {k: float(v) for k, v in info.items()}            # the only host sync of the loop
+            if vals.get("status", 0) == 2:
+                raise AssertionError("hard-negative threshold reached 0 (reference assert, models/ssd_model.py:375)")
+            logger.info("%s step %d: %s", stage, step, vals)
+
+    def train(self, data_loader, cfg):
+        if cfg.warmup is True:
+            assert cfg.warmup_optimizer is not None, "Define a warmup optimizer if you want to enable warmup!"
+        try:
+            self._train(data_loader, cfg)
+        except Exception:
+            self.save("error_exit_save.pt")
+            logger.critical("Error occurred while training, last model weight is saved to 'error_exit_save.pt'")
+            raise
+
+    # ------------------------------------------------------------------ inference (A9 + A9')
+    def detect(self, image, score_thresh=0.3, iou_thresh=0.45, max_cand=400):
+        """image f32 [B,300,300,3] in [-1,1] -> (score, cls, box_px, keep) device tensors [B,A(,4)].
+        Scoring/decoding as the reference's visualize(); `keep` adds per-class NMS (no reference counterpart)."""
+        x = ops.image_prep(image.contiguous(), normalize=False)
+        loc, conf = self._engine.forward(x)
+        score, cls, box, cand = ops.score_decode(conf, loc, self._pset, score_thresh, float(self.cfg.input_shape[0]))
+        keep = ops.nms(score, cls, box, cand, iou_thresh, max_cand)
+        return score, cls, box, keep
+
+    # ------------------------------------------------------------------ checkpoint
+    def save(self, path="model_weight.pt"):
+        d = os.path.dirname(path)
+        if d:
+            os.makedirs(d, exist_ok=True)
+        torch.save(self._engine.state_dict(), path)
+        logger.info("Model is saved to %s", path)
+
+    def load(self, path="model_weight.pt"):
+        self._engine.load_state_dict(torch.load(path, map_location="cpu", weights_only=False))
+        logger.info("Model is loaded from %s", path)

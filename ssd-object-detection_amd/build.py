@@ -21,7 +21,7 @@ PER_FILE = {
     # bit-exact IEEE arithmetic vs numpy: no FMA contraction.  -fno-honor-nans only drops the
     # sNaN-quieting v_max(x,x) in front of every fmax/fmin (inputs are finite by contract).
     "match.hip": ["-ffp-contract=off", "-fno-honor-nans"],
-    "nms.hip": ["-ffp-contract=off", "-fno-honor-nans"],
+    "detect.hip": ["-ffp-contract=off"],
 }
 
 

@@ -25,6 +25,7 @@
 //                  of ones.
 #include "common.h"
 #include <hip/hip_bf16.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -98,6 +99,65 @@ __device__ __forceinline__ bf16_raw f2bf(float f) {
 // slots XOR-swizzled so that 16 consecutive rows reading the same chunk hit 16 different slots.
 __device__ __forceinline__ int swz(int row, int chunk) {
     return (row >> 1) * 256 + ((((row & 1) << 3) | (chunk ^ ((row >> 1) & 7))) << 4);
+}
+
+// Epilogue shared by the implicit-GEMM kernels: lane holds channels n_base + (lane>>4)*4 + {0..3} of pixel
+// m_base + (lane&15) for every (channel tile, pixel tile) of its wave.
+template <int BN, int EPI, int CT, int PT>
+__device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[CT][PT], const ConvGeom& g, const Epilogue& ep, int m0,
+                                              int n0, int wave_m, int wave_n, int lane) {
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const int m = m0 + wave_m * 64 + p * 16 + (lane & 15);
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int n = n0 + wave_n * (16 * CT) + c * 16 + (lane >> 4) * 4;
+            if (n >= g.N) continue;
+            float v[4] = {acc[c][p][0], acc[c][p][1], acc[c][p][2], acc[c][p][3]};
+            if constexpr (EPI == EPI_FWD) {
+                if (ep.bias) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (n + j < g.N) v[j] += ep.bias[n + j];
+                }
+                if (ep.relu) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                }
+                bf16_raw* o = ep.out + (long long)m * ep.ldo + n;
+                if (n + 3 < g.N) {
+                    *reinterpret_cast<uint2*>(o) = make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16),
+                                                              (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (n + j < g.N) o[j] = f2bf(v[j]);
+                }
+            } else if constexpr (EPI == EPI_DGRAD) {
+                bf16_raw* o = ep.out + (long long)m * ep.ldo + n;
+                const bf16_raw* ms = ep.mask_src ? ep.mask_src + (long long)m * ep.ldo + n : nullptr;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (n + j >= g.N) continue;
+                    float r = v[j];
+                    if (ep.accumulate) r += bf2f(o[j]);
+                    if (ms && !(bf2f(ms[j]) > 0.f)) r = 0.f;
+                    o[j] = f2bf(r);
+                }
+            } else {  // EPI_HEAD: scatter into loc [B][A][4] and conf [B][A][classes]
+                const int b = fdiv(m, g.d_hw);
+                const int pix = m - b * g.d_hw.d;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int nn = n + j;
+                    if (nn >= ep.n_loc + ep.n_conf) continue;
+                    const float r = v[j] + (ep.bias ? ep.bias[nn] : 0.f);
+                    const long long anchor0 = (long long)b * ep.anchors_total + ep.level_off + (long long)pix * ep.per_cell;
+                    if (nn < ep.n_loc) ep.loc[anchor0 * 4 + nn] = f2bf(r);
+                    else ep.conf[anchor0 * ep.classes + (nn - ep.n_loc)] = f2bf(r);
+                }
+            }
+        }
+    }
 }
 
 template <int BN, int EPI>
@@ -210,59 +270,137 @@ __global__ __launch_bounds__(WG) void k_conv_igemm(const bf16_raw* __restrict__ 
         __syncthreads();
     }
 
-    // epilogue: lane holds channels n_base + (lane>>4)*4 + {0..3} of pixel m_base + (lane&15)
+    conv_epilogue<BN, EPI, CT, PT>(acc, g, ep, m0, n0, wave_m, wave_n, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Implicit GEMM, LDS-DMA version: tiles go global -> LDS directly (global_load_lds_dwordx4: per-lane
+// gather address, wave-uniform 1 KiB LDS destination, no VGPR staging, no ds_write).  The swizzled LDS
+// image is produced by choosing which chunk each lane fetches: wave-instruction i fills bank rows
+// 4i..4i+3 = tile rows 8i..8i+7; lane L owns slot L of that KiB.  Padding / out-of-range chunks are
+// fetched from a 16-byte zero block.  Schedule per k-step (two LDS buffers, ONE barrier):
+//   wait vmcnt(0) + barrier  -> tile ks has landed everywhere and everybody is done reading tile ks-1
+//   issue the DMA of tile ks+1 into the other buffer (in flight during this step's MFMAs)
+//   read fragments of tile ks, 64 MFMAs.
+__device__ __attribute__((aligned(16))) const unsigned g_zero16[4] = {0u, 0u, 0u, 0u};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+
+template <int BM, int BN, int EPI>
+__global__ __launch_bounds__((BM / 64) * (BN >= 128 ? BN / 64 : 2) * 64) void k_conv_igemm_dma(
+    const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ w, ConvGeom g, Epilogue ep) {
+    constexpr int WAVES_M = BM / 64;
+    constexpr int WAVES_N = BN >= 128 ? BN / 64 : 2;
+    constexpr int NW = WAVES_M * WAVES_N;       // waves per workgroup (4, 8 or 16)
+    constexpr int CT = BN / (16 * WAVES_N);     // 16-wide channel tiles per wave (4, or 2 for BN = 64)
+    constexpr int PT = 4;                       // 16-wide pixel tiles per wave
+    constexpr int XI = BM / 8 / NW;             // activation DMA instructions per wave per k-step
+    constexpr int WI = BN / 8 / NW;             // weight DMA instructions per wave per k-step
+    static_assert(XI >= 1 && WI >= 1, "tile too small for the wave count");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    auto s_x = [&](int buf) { return smem + buf * ((BM + BN) * 128); };
+    auto s_w = [&](int buf) { return smem + buf * ((BM + BN) * 128) + BM * 128; };
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave % WAVES_M, wave_n = wave / WAVES_M;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+    // DMA ownership: wave-instruction i = (wave&1) + 2*((wave>>1) + (NW/2)*j) covers tile rows 8i..8i+7 (i has the
+    // wave's parity, so a lane fetches the same k-chunk for all of its rows);
+    // lane L -> row 8i + 2*(L>>4) + ((L>>3)&1), chunk (L&7) ^ ((row>>1)&7) = (L&7) ^ (4*(wave&1) + (L>>4))
+    const int rl = 2 * (lane >> 4) + ((lane >> 3) & 1);
+    const int slot = (lane & 7) ^ (4 * (wave & 1) + (lane >> 4));
+    int ybase[XI], xbase[XI];
+    long long ibase[XI];
+    bool mvalid[XI];
 #pragma unroll
-    for (int p = 0; p < PT; ++p) {
-        const int m = m0 + wave_m * 64 + p * 16 + (lane & 15);
-        if (m >= g.M) continue;
+    for (int j = 0; j < XI; ++j) {
+        const int i = (wave & 1) + 2 * ((wave >> 1) + (NW / 2) * j);
+        const int m = m0 + 8 * i + rl;
+        mvalid[j] = m < g.M;
+        const int mm = mvalid[j] ? m : 0;
+        const int b = fdiv(mm, g.d_hw);
+        const int rem = mm - b * g.d_hw.d;
+        const int oy = fdiv(rem, g.d_w);
+        const int ox = rem - oy * g.d_w.d;
+        ybase[j] = oy * g.mul - g.pad_t;
+        xbase[j] = ox * g.mul - g.pad_l;
+        ibase[j] = (long long)b * g.H * g.W;
+    }
+    long long wrow[WI];
+    bool wvalid[WI];
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            const int n = n0 + wave_n * (BN / 2) + c * 16 + (lane >> 4) * 4;
-            if (n >= g.N) continue;
-            float v[4] = {acc[c][p][0], acc[c][p][1], acc[c][p][2], acc[c][p][3]};
-            if constexpr (EPI == EPI_FWD) {
-                if (ep.bias) {
+    for (int j = 0; j < WI; ++j) {
+        const int i = (wave & 1) + 2 * ((wave >> 1) + (NW / 2) * j);
+        const int n = n0 + 8 * i + rl;
+        wvalid[j] = n < g.N;
+        wrow[j] = (long long)(wvalid[j] ? n : 0) * g.ldw;
+    }
+    int tap = slot / g.cpt, cc = slot - tap * g.cpt;
+    int kh = tap / g.KW, kw = tap - kh * g.KW;
+    int q = slot;
+    const int dmask = g.div - 1, dshift = g.div > 1 ? 1 : 0;   // div is 1 or 2
+
+    auto issue_dma = [&](int buf) {
+        const bool kvalid = q < g.nchunks;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (n + j < g.N) v[j] += ep.bias[n + j];
-                }
-                if (ep.relu) {
+        for (int j = 0; j < XI; ++j) {
+            const int i = (wave & 1) + 2 * ((wave >> 1) + (NW / 2) * j);
+            const int ny = ybase[j] + kh, nx = xbase[j] + kw;
+            const int iy = ny >> dshift, ix = nx >> dshift;
+            const bool ok = kvalid && mvalid[j] && ((ny | nx) >= 0) && (((ny | nx) & dmask) == 0) && iy < g.H && ix < g.W;
+            const bf16_raw* src = ok ? x + ((ibase[j] + (long long)iy * g.W + ix) * g.C + cc * 8)
+                                     : reinterpret_cast<const bf16_raw*>(g_zero16);
+            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(s_x(buf) + i * 1024), 16, 0, 0);
+        }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-                }
-                bf16_raw* o = ep.out + (long long)m * ep.ldo + n;
-                if (n + 3 < g.N) {
-                    *reinterpret_cast<uint2*>(o) = make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16),
-                                                              (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
-                } else {
+        for (int j = 0; j < WI; ++j) {
+            const int i = (wave & 1) + 2 * ((wave >> 1) + (NW / 2) * j);
+            const bf16_raw* src = (kvalid && wvalid[j]) ? w + (wrow[j] + (long long)q * 8)
+                                                        : reinterpret_cast<const bf16_raw*>(g_zero16);
+            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(s_w(buf) + i * 1024), 16, 0, 0);
+        }
+        q += 8;
+        cc += 8;
+        while (cc >= g.cpt) {
+            cc -= g.cpt;
+            if (++kw == g.KW) { kw = 0; ++kh; }
+        }
+    };
+
+    f32x4_t acc[CT][PT];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (n + j < g.N) o[j] = f2bf(v[j]);
-                }
-            } else if constexpr (EPI == EPI_DGRAD) {
-                bf16_raw* o = ep.out + (long long)m * ep.ldo + n;
-                const bf16_raw* ms = ep.mask_src ? ep.mask_src + (long long)m * ep.ldo + n : nullptr;
+    for (int c = 0; c < CT; ++c)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (n + j >= g.N) continue;
-                    float r = v[j];
-                    if (ep.accumulate) r += bf2f(o[j]);
-                    if (ms && !(bf2f(ms[j]) > 0.f)) r = 0.f;
-                    o[j] = f2bf(r);
-                }
-            } else {  // EPI_HEAD: scatter into loc [B][A][4] and conf [B][A][classes]
-                const int b = fdiv(m, g.d_hw);
-                const int pix = m - b * g.d_hw.d;
+        for (int p = 0; p < PT; ++p) acc[c][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nks = (g.nchunks + 7) >> 3;
+    issue_dma(0);
+    const int frow = lane & 15, fk = lane >> 4;
+    for (int ks = 0; ks < nks; ++ks) {
+        const int cur = ks & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (ks + 1 < nks) issue_dma(cur ^ 1);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int nn = n + j;
-                    if (nn >= ep.n_loc + ep.n_conf) continue;
-                    const float r = v[j] + (ep.bias ? ep.bias[nn] : 0.f);
-                    const long long anchor0 = (long long)b * ep.anchors_total + ep.level_off + (long long)pix * ep.per_cell;
-                    if (nn < ep.n_loc) ep.loc[anchor0 * 4 + nn] = f2bf(r);
-                    else ep.conf[anchor0 * ep.classes + (nn - ep.n_loc)] = f2bf(r);
-                }
-            }
+        for (int ksub = 0; ksub < 2; ++ksub) {
+            bf16x8_t fx[PT], fw[CT];
+#pragma unroll
+            for (int p = 0; p < PT; ++p)
+                fx[p] = *reinterpret_cast<const bf16x8_t*>(s_x(cur) + swz(wave_m * 64 + p * 16 + frow, ksub * 4 + fk));
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+                fw[c] = *reinterpret_cast<const bf16x8_t*>(s_w(cur) + swz(wave_n * (16 * CT) + c * 16 + frow, ksub * 4 + fk));
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int p = 0; p < PT; ++p)
+                    acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[c], fx[p], acc[c][p], 0, 0, 0);
         }
     }
+    conv_epilogue<BN, EPI, CT, PT>(acc, g, ep, m0, n0, wave_m, wave_n, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -562,11 +700,58 @@ ConvGeom make_geom(int B, int H, int W, int C, int Ho, int Wo, int N, int KH, in
     return g;
 }
 
+int igemm_variant() {                       // SSD_CONV_VARIANT=0: register-staged kernel, 1 (default): LDS-DMA kernel
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("SSD_CONV_VARIANT");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+
 template <int EPI>
 int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue& ep, hipStream_t s) {
     const bf16_raw* xp = static_cast<const bf16_raw*>(x);
     const bf16_raw* wp = static_cast<const bf16_raw*>(w);
     const unsigned gm = (unsigned)((g.M + 127) / 128);
+    if (igemm_variant() >= 1) {
+        // tile choice: the CU ingests ~28 B/clk from L2, so MACs per staged byte decide the ceiling: prefer the
+        // largest tile that still gives every CU work (>= ~2 workgroups per CU), SSD_CONV_TILE overrides (testing)
+        static int force = -1;
+        if (force < 0) { const char* e = getenv("SSD_CONV_TILE"); force = e ? atoi(e) : 0; }
+        const long long wg_128 = (long long)((g.M + 127) / 128);
+        const long long wg_256 = (long long)((g.M + 255) / 256);
+        int bm = 128, bn = g.N <= 64 ? 64 : 128;
+        if (g.N > 128 && wg_256 * ((g.N + 255) / 256) >= 384) { bm = 256; bn = 256; }
+        else if (g.N > 64 && wg_256 * ((g.N + 127) / 128) >= 384) { bm = 256; bn = 128; }
+        else if (g.N <= 64 && wg_256 >= 384) { bm = 256; bn = 64; }
+        if (force == 1) { bm = 128; bn = g.N <= 64 ? 64 : 128; }
+        (void)wg_128;
+#define SSD_LAUNCH_DMA(BM_, BN_)                                                                                   \
+        do {                                                                                                       \
+            constexpr int NT_ = (BM_ / 64) * (BN_ >= 128 ? BN_ / 64 : 2) * 64;                                      \
+            const size_t lds_ = 2 * (BM_ + BN_) * 128;                                                             \
+            auto kern_ = k_conv_igemm_dma<BM_, BN_, EPI>;                                                          \
+            if (lds_ > 65536) {                                                                                    \
+                static bool set_ = false;                                                                          \
+                if (!set_) {                                                                                       \
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern_),                                   \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_) != hipSuccess)   \
+                        return SSD_ERR_LAUNCH;                                                                     \
+                    set_ = true;                                                                                   \
+                }                                                                                                  \
+            }                                                                                                      \
+            hipLaunchKernelGGL(kern_, dim3((unsigned)((g.M + BM_ - 1) / BM_), (unsigned)((g.N + BN_ - 1) / BN_)),   \
+                               dim3(NT_), lds_, s, xp, wp, g, ep);                                                 \
+        } while (0)
+        if (bm == 256 && bn == 256) SSD_LAUNCH_DMA(256, 256);
+        else if (bm == 256 && bn == 128) SSD_LAUNCH_DMA(256, 128);
+        else if (bm == 256 && bn == 64) SSD_LAUNCH_DMA(256, 64);
+        else if (bn == 64) SSD_LAUNCH_DMA(128, 64);
+        else SSD_LAUNCH_DMA(128, 128);
+#undef SSD_LAUNCH_DMA
+        return ssd_launch_status();
+    }
     if (g.N <= 64) {
         const size_t lds = 2 * (128 + 64) * 128;
         hipLaunchKernelGGL((k_conv_igemm<64, EPI>), dim3(gm, (unsigned)((g.N + 63) / 64)), dim3(WG), lds, s, xp, wp, g, ep);

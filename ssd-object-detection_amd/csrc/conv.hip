@@ -68,6 +68,7 @@ struct ConvGeom {
     int ldw;                                 // weight row stride (elements) = KH*KW*C
     int cpt;                                 // chunks per tap = C/8
     FastDiv d_hw, d_w;                       // divide by Ho*Wo and by Wo
+    int ablate;                              // dev only (SSD_ABLATE): 1 no DMA after the prologue, 2 no wait/barrier, 4 no MFMA
 };
 
 enum { EPI_FWD = 0, EPI_HEAD = 1, EPI_DGRAD = 2 };
@@ -103,29 +104,39 @@ __device__ __forceinline__ int swz(int row, int chunk) {
 
 // Epilogue shared by the implicit-GEMM kernels: lane holds channels n_base + (lane>>4)*4 + {0..3} of pixel
 // m_base + (lane&15) for every (channel tile, pixel tile) of its wave.
-template <int BN, int EPI, int CT, int PT>
-__device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[CT][PT], const ConvGeom& g, const Epilogue& ep, int m0,
-                                              int n0, int wave_m, int wave_n, int lane) {
+template <int EPI, int CT, int PT>
+__device__ __forceinline__ void conv_epilogue_rows(f32x4_t (&acc)[CT][PT], const ConvGeom& g, const Epilogue& ep,
+                                                   const int (&mrow)[PT], int nbase, int lane) {
+    // mrow[p]: flat output pixel of this lane for pixel tile p (-1: outside); nbase: first channel of the wave
 #pragma unroll
-    for (int p = 0; p < PT; ++p) {
-        const int m = m0 + wave_m * 64 + p * 16 + (lane & 15);
-        if (m >= g.M) continue;
+    for (int c = 0; c < CT; ++c) {
+        const int n = nbase + c * 16 + (lane >> 4) * 4;
+        if (n >= g.N) continue;
+        const bool full = n + 3 < g.N;
+        float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (EPI == EPI_FWD || EPI == EPI_HEAD) {
+            if (ep.bias) {
+                if (full) {
+                    const float4 bv = *reinterpret_cast<const float4*>(ep.bias + n);
+                    bias4[0] = bv.x; bias4[1] = bv.y; bias4[2] = bv.z; bias4[3] = bv.w;
+                } else {
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            const int n = n0 + wave_n * (16 * CT) + c * 16 + (lane >> 4) * 4;
-            if (n >= g.N) continue;
-            float v[4] = {acc[c][p][0], acc[c][p][1], acc[c][p][2], acc[c][p][3]};
-            if constexpr (EPI == EPI_FWD) {
-                if (ep.bias) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) if (n + j < g.N) v[j] += ep.bias[n + j];
+                    for (int j = 0; j < 4; ++j) if (n + j < g.N) bias4[j] = ep.bias[n + j];
                 }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            const int m = mrow[p];
+            if (m < 0) continue;
+            float v[4] = {acc[c][p][0] + bias4[0], acc[c][p][1] + bias4[1], acc[c][p][2] + bias4[2], acc[c][p][3] + bias4[3]};
+            if constexpr (EPI == EPI_FWD) {
                 if (ep.relu) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
                 }
                 bf16_raw* o = ep.out + (long long)m * ep.ldo + n;
-                if (n + 3 < g.N) {
+                if (full) {
                     *reinterpret_cast<uint2*>(o) = make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16),
                                                               (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
                 } else {
@@ -135,29 +146,57 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[CT][PT], const Conv
             } else if constexpr (EPI == EPI_DGRAD) {
                 bf16_raw* o = ep.out + (long long)m * ep.ldo + n;
                 const bf16_raw* ms = ep.mask_src ? ep.mask_src + (long long)m * ep.ldo + n : nullptr;
+                if (full) {
+                    if (ep.accumulate) {
+                        const uint2 old = *reinterpret_cast<const uint2*>(o);
+                        v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
+                        v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
+                    }
+                    if (ms) {
+                        const uint2 mk = *reinterpret_cast<const uint2*>(ms);
+                        if (!(__uint_as_float(mk.x << 16) > 0.f)) v[0] = 0.f;
+                        if (!(__uint_as_float(mk.x & 0xffff0000u) > 0.f)) v[1] = 0.f;
+                        if (!(__uint_as_float(mk.y << 16) > 0.f)) v[2] = 0.f;
+                        if (!(__uint_as_float(mk.y & 0xffff0000u) > 0.f)) v[3] = 0.f;
+                    }
+                    *reinterpret_cast<uint2*>(o) = make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16),
+                                                              (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (n + j >= g.N) continue;
-                    float r = v[j];
-                    if (ep.accumulate) r += bf2f(o[j]);
-                    if (ms && !(bf2f(ms[j]) > 0.f)) r = 0.f;
-                    o[j] = f2bf(r);
+                    for (int j = 0; j < 4; ++j) {
+                        if (n + j >= g.N) continue;
+                        float r = v[j];
+                        if (ep.accumulate) r += bf2f(o[j]);
+                        if (ms && !(bf2f(ms[j]) > 0.f)) r = 0.f;
+                        o[j] = f2bf(r);
+                    }
                 }
             } else {  // EPI_HEAD: scatter into loc [B][A][4] and conf [B][A][classes]
                 const int b = fdiv(m, g.d_hw);
                 const int pix = m - b * g.d_hw.d;
+                const long long anchor0 = (long long)b * ep.anchors_total + ep.level_off + (long long)pix * ep.per_cell;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int nn = n + j;
                     if (nn >= ep.n_loc + ep.n_conf) continue;
-                    const float r = v[j] + (ep.bias ? ep.bias[nn] : 0.f);
-                    const long long anchor0 = (long long)b * ep.anchors_total + ep.level_off + (long long)pix * ep.per_cell;
-                    if (nn < ep.n_loc) ep.loc[anchor0 * 4 + nn] = f2bf(r);
-                    else ep.conf[anchor0 * ep.classes + (nn - ep.n_loc)] = f2bf(r);
+                    if (nn < ep.n_loc) ep.loc[anchor0 * 4 + nn] = f2bf(v[j]);
+                    else ep.conf[anchor0 * ep.classes + (nn - ep.n_loc)] = f2bf(v[j]);
                 }
             }
         }
     }
+}
+
+template <int BN, int EPI, int CT, int PT>
+__device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[CT][PT], const ConvGeom& g, const Epilogue& ep, int m0,
+                                              int n0, int wave_m, int wave_n, int lane) {
+    int mrow[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const int m = m0 + wave_m * 64 + p * 16 + (lane & 15);
+        mrow[p] = m < g.M ? m : -1;
+    }
+    conv_epilogue_rows<EPI, CT, PT>(acc, g, ep, mrow, n0 + wave_n * (16 * CT), lane);
 }
 
 template <int BN, int EPI>
@@ -305,38 +344,42 @@ __global__ __launch_bounds__((BM / 64) * (BN >= 128 ? BN / 64 : 2) * 64) void k_
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave % WAVES_M, wave_n = wave / WAVES_M;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // XCD-aware tile order: workgroup L runs on XCD L % 8 (round-robin dispatch); the N-tiles of one pixel tile are
+    // consecutive on ONE XCD so that the gathered activation tile is fetched into that XCD's L2 once.
+    const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
+    const int kx = blockIdx.x >> 3;
+    const int mt = (kx / ntn) * 8 + (blockIdx.x & 7);
+    if (mt >= ntm) return;
+    const int m0 = mt * BM, n0 = (kx % ntn) * BN;
 
     // DMA ownership: wave-instruction i = (wave&1) + 2*((wave>>1) + (NW/2)*j) covers tile rows 8i..8i+7 (i has the
     // wave's parity, so a lane fetches the same k-chunk for all of its rows);
     // lane L -> row 8i + 2*(L>>4) + ((L>>3)&1), chunk (L&7) ^ ((row>>1)&7) = (L&7) ^ (4*(wave&1) + (L>>4))
     const int rl = 2 * (lane >> 4) + ((lane >> 3) & 1);
     const int slot = (lane & 7) ^ (4 * (wave & 1) + (lane >> 4));
-    int ybase[XI], xbase[XI];
-    long long ibase[XI];
-    bool mvalid[XI];
+    // per staged row: (ybase, xbase) = source coordinate of tap (0,0) times div, rowpix = flat source pixel of it
+    // (div == 1).  An invalid row gets ybase far outside so that every tap fails the range test.
+    int ybase[XI], xbase[XI], ibase[XI];
 #pragma unroll
     for (int j = 0; j < XI; ++j) {
         const int i = (wave & 1) + 2 * ((wave >> 1) + (NW / 2) * j);
         const int m = m0 + 8 * i + rl;
-        mvalid[j] = m < g.M;
-        const int mm = mvalid[j] ? m : 0;
+        const bool mv = m < g.M;
+        const int mm = mv ? m : 0;
         const int b = fdiv(mm, g.d_hw);
         const int rem = mm - b * g.d_hw.d;
         const int oy = fdiv(rem, g.d_w);
         const int ox = rem - oy * g.d_w.d;
-        ybase[j] = oy * g.mul - g.pad_t;
+        ybase[j] = mv ? oy * g.mul - g.pad_t : -(1 << 20);
         xbase[j] = ox * g.mul - g.pad_l;
-        ibase[j] = (long long)b * g.H * g.W;
+        ibase[j] = b * g.H * g.W;              // < 2^31 (checked on the host)
     }
-    long long wrow[WI];
-    bool wvalid[WI];
+    unsigned wrow[WI];                          // element offset of the weight row, ~0u if out of range (weights < 4G elements)
 #pragma unroll
     for (int j = 0; j < WI; ++j) {
         const int i = (wave & 1) + 2 * ((wave >> 1) + (NW / 2) * j);
         const int n = n0 + 8 * i + rl;
-        wvalid[j] = n < g.N;
-        wrow[j] = (long long)(wvalid[j] ? n : 0) * g.ldw;
+        wrow[j] = n < g.N ? (unsigned)n * (unsigned)g.ldw : ~0u;
     }
     int tap = slot / g.cpt, cc = slot - tap * g.cpt;
     int kh = tap / g.KW, kw = tap - kh * g.KW;
@@ -350,16 +393,17 @@ __global__ __launch_bounds__((BM / 64) * (BN >= 128 ? BN / 64 : 2) * 64) void k_
             const int i = (wave & 1) + 2 * ((wave >> 1) + (NW / 2) * j);
             const int ny = ybase[j] + kh, nx = xbase[j] + kw;
             const int iy = ny >> dshift, ix = nx >> dshift;
-            const bool ok = kvalid && mvalid[j] && ((ny | nx) >= 0) && (((ny | nx) & dmask) == 0) && iy < g.H && ix < g.W;
-            const bf16_raw* src = ok ? x + ((ibase[j] + (long long)iy * g.W + ix) * g.C + cc * 8)
-                                     : reinterpret_cast<const bf16_raw*>(g_zero16);
+            // unsigned compares fold the >= 0 tests; the element offset fits 32 bits (tensor < 4G elements, host check)
+            const bool ok = kvalid && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W && (((ny | nx) & dmask) == 0);
+            const unsigned off = (unsigned)(ibase[j] + iy * g.W + ix) * (unsigned)g.C + (unsigned)(cc * 8);
+            const bf16_raw* src = ok ? x + off : reinterpret_cast<const bf16_raw*>(g_zero16);
             __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(s_x(buf) + i * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < WI; ++j) {
             const int i = (wave & 1) + 2 * ((wave >> 1) + (NW / 2) * j);
-            const bf16_raw* src = (kvalid && wvalid[j]) ? w + (wrow[j] + (long long)q * 8)
-                                                        : reinterpret_cast<const bf16_raw*>(g_zero16);
+            const bf16_raw* src = (kvalid && wrow[j] != ~0u) ? w + (wrow[j] + (unsigned)(q * 8))
+                                                             : reinterpret_cast<const bf16_raw*>(g_zero16);
             __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(s_w(buf) + i * 1024), 16, 0, 0);
         }
         q += 8;
@@ -381,9 +425,11 @@ __global__ __launch_bounds__((BM / 64) * (BN >= 128 ? BN / 64 : 2) * 64) void k_
     const int frow = lane & 15, fk = lane >> 4;
     for (int ks = 0; ks < nks; ++ks) {
         const int cur = ks & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (ks + 1 < nks) issue_dma(cur ^ 1);
+        if (!(g.ablate & 2)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (ks + 1 < nks && !(g.ablate & 1)) issue_dma(cur ^ 1);
 #pragma unroll
         for (int ksub = 0; ksub < 2; ++ksub) {
             bf16x8_t fx[PT], fw[CT];
@@ -393,14 +439,165 @@ __global__ __launch_bounds__((BM / 64) * (BN >= 128 ? BN / 64 : 2) * 64) void k_
 #pragma unroll
             for (int c = 0; c < CT; ++c)
                 fw[c] = *reinterpret_cast<const bf16x8_t*>(s_w(cur) + swz(wave_n * (16 * CT) + c * 16 + frow, ksub * 4 + fk));
+            if (g.ablate & 4) {
+#pragma unroll
+                for (int p = 0; p < PT; ++p) asm volatile("" ::"v"(fx[p]));
+#pragma unroll
+                for (int c = 0; c < CT; ++c) asm volatile("" ::"v"(fw[c]));
+            } else {
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+#pragma unroll
+                    for (int p = 0; p < PT; ++p)
+                        acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[c], fx[p], acc[c][p], 0, 0, 0);
+            }
+        }
+    }
+    conv_epilogue<BN, EPI, CT, PT>(acc, g, ep, m0, n0, wave_m, wave_n, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution with an LDS-resident input patch (forward, and data gradient with the
+// transposed weights).  A workgroup owns a 16x16 block of output pixels of one image and BN output channels.
+// Per 64-channel chunk of the input, the 18x18-pixel halo patch is brought into LDS ONCE (LDS-DMA) and all nine
+// taps read their MFMA fragments from it at shifted addresses; only the [BN][64] weight slice of each tap is
+// streamed (double-buffered).  Compared with the generic implicit GEMM this removes the 9x re-staging of the
+// activations: ~100 MACs per byte brought into the CU even at N = 64, where the generic 256x64 tile has 26 and
+// is bound by the CU's ~28 B/clk L2 ingest.
+constexpr int PATCH_W = 18;
+constexpr int PATCH_PIX = PATCH_W * PATCH_W;               // 324
+constexpr int PATCH_INSTR = (PATCH_PIX * 8 + 63) / 64;     // 41 one-KiB DMA instructions
+constexpr int PATCH_BYTES = PATCH_INSTR * 1024;            // 41984
+
+template <int BN, int EPI>
+__global__ __launch_bounds__(512) void k_conv3x3_patch(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ w,
+                                                       ConvGeom g, Epilogue ep, int tiles_x, int tiles_y) {
+    constexpr int CT = BN / 32;
+    constexpr int PT = 4;
+    constexpr int WI = BN / 64;                              // weight DMA instructions per wave per tap
+    constexpr int PI = (PATCH_INSTR + 7) / 8;                // patch DMA instructions per wave per chunk (<= 6)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    auto s_w = [&](int buf) { return smem + buf * (BN * 128); };           // 3 weight buffers (two taps ahead)
+    auto s_p = [&](int buf) { return smem + 3 * (BN * 128) + buf * PATCH_BYTES; };
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave & 3, wave_n = wave >> 2;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int y0 = ty * 16, x0 = tx * 16, n0 = blockIdx.y * BN;
+
+    // patch DMA ownership: instruction i = wave + 8j; lane L fills 16-byte slot S = 64 i + L of the swizzled image
+    long long poff[PI];
+#pragma unroll
+    for (int j = 0; j < PI; ++j) {
+        const int i = wave + 8 * j;
+        const int S = i * 64 + lane;
+        const int pr = S >> 4, pos = S & 15;
+        const int pp = 2 * pr + (pos >> 3);
+        const int c = (pos & 7) ^ (pr & 7);
+        const int py = pp / PATCH_W, px = pp - py * PATCH_W;
+        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+        const bool ok = i < PATCH_INSTR && pp < PATCH_PIX && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+        poff[j] = ok ? (((long long)b * g.H + iy) * g.W + ix) * g.C + c * 8 : -1;
+    }
+    // weight DMA ownership (same scheme as k_conv_igemm_dma, 8 waves)
+    const int rl = 2 * (lane >> 4) + ((lane >> 3) & 1);
+    const int wslot = (lane & 7) ^ (4 * (wave & 1) + (lane >> 4));
+    long long woff[WI];
+#pragma unroll
+    for (int j = 0; j < WI; ++j) {
+        const int i = (wave & 1) + 2 * ((wave >> 1) + 4 * j);
+        const int n = n0 + 8 * i + rl;
+        woff[j] = n < g.N ? (long long)n * g.ldw + wslot * 8 : -1;
+    }
+    const int nchunk = g.C >> 6;
+    const int nsteps = nchunk * 9;
+
+    auto dma_patch = [&](int chunk, int buf) {
+#pragma unroll
+        for (int j = 0; j < PI; ++j) {
+            const int i = wave + 8 * j;
+            if (i < PATCH_INSTR) {
+                const bf16_raw* src = poff[j] >= 0 ? x + poff[j] + chunk * 64 : reinterpret_cast<const bf16_raw*>(g_zero16);
+                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(s_p(buf) + i * 1024), 16, 0, 0);
+            }
+        }
+    };
+    auto dma_w = [&](int step, int buf) {
+        const int chunk = step / 9, tap = step - chunk * 9;
+#pragma unroll
+        for (int j = 0; j < WI; ++j) {
+            const int i = (wave & 1) + 2 * ((wave >> 1) + 4 * j);
+            const bf16_raw* src = woff[j] >= 0 ? w + woff[j] + tap * g.C + chunk * 64 : reinterpret_cast<const bf16_raw*>(g_zero16);
+            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(s_w(buf) + i * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4_t acc[CT][PT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int p = 0; p < PT; ++p) acc[c][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // Counted waits: DMAs complete in issue order, so "all but the N newest" = everything issued before the
+    // previous step's batch.  A step's batch = WI weight instructions (+ this wave's patch instructions when the
+    // next chunk's patch is prefetched, at tap 0).
+    const int my_patch = wave == 0 ? (PATCH_INSTR + 7) / 8 : (PATCH_INSTR - wave + 7) / 8;
+    auto wait_all_but = [&](int n) {
+        switch (n) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+    };
+    dma_patch(0, 0);
+    dma_w(0, 0);
+    if (nsteps > 1) dma_w(1, 1);
+    int last_batch = nsteps > 1 ? WI : 0;          // instructions issued after the data step 0 needs
+    const int frow = lane & 15, fk = lane >> 4;
+    int chunk = 0, tap = 0, kh = 0, kw = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        wait_all_but(last_batch);
+        asm volatile("s_barrier" ::: "memory");
+        last_batch = 0;
+        if (s + 2 < nsteps) { dma_w(s + 2, (s + 2) % 3); last_batch += WI; }
+        if (tap == 0 && chunk + 1 < nchunk) { dma_patch(chunk + 1, (chunk + 1) & 1); last_batch += my_patch; }
+        const char* pb = s_p(chunk & 1);
+        const char* wb = s_w(s % 3);
+#pragma unroll
+        for (int ksub = 0; ksub < 2; ++ksub) {
+            bf16x8_t fx[PT], fw[CT];
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                const int pix = (4 * wave_m + p + kh) * PATCH_W + kw + frow;
+                fx[p] = *reinterpret_cast<const bf16x8_t*>(pb + swz(pix, ksub * 4 + fk));
+            }
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+                fw[c] = *reinterpret_cast<const bf16x8_t*>(wb + swz(wave_n * (16 * CT) + c * 16 + frow, ksub * 4 + fk));
 #pragma unroll
             for (int c = 0; c < CT; ++c)
 #pragma unroll
                 for (int p = 0; p < PT; ++p)
                     acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[c], fx[p], acc[c][p], 0, 0, 0);
         }
+        if (++kw == 3) { kw = 0; ++kh; }
+        if (++tap == 9) { tap = 0; kh = 0; kw = 0; ++chunk; }
     }
-    conv_epilogue<BN, EPI, CT, PT>(acc, g, ep, m0, n0, wave_m, wave_n, lane);
+    int mrow[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const int y = y0 + 4 * wave_m + p, xx = x0 + (lane & 15);
+        mrow[p] = (y < g.Ho && xx < g.Wo) ? (b * g.Ho + y) * g.Wo + xx : -1;
+    }
+    conv_epilogue_rows<EPI, CT, PT>(acc, g, ep, mrow, n0 + wave_n * (16 * CT), lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -543,6 +740,202 @@ __global__ __launch_bounds__(WG) void k_conv_wgrad(const bf16_raw* __restrict__ 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int co = co0 + wave_m * 64 + a * 16 + (lane >> 4) * 4 + j;
+                if (co < g.N) ob[co] = accb[a][j];
+            }
+    }
+}
+
+// Weight gradient, LDS-DMA version with larger tiles: BMO output channels x BNC (tap,ci) columns per workgroup,
+// (BMO/64)x(BNC/64) waves of 64x64, 64 pixels per step, two LDS buffers, one barrier per step.  Tiles are
+// [pixel][channel] images written by global_load_lds (1 KiB per wave-instruction); the 32-byte column groups of
+// each pixel row are XOR-permuted by key(row) = (row&3) | ((row>>3)&1)<<2 so that the eight rows a half-wave
+// touches in one transposing read (ds_read_b64_tr_b16) fall on eight different bank groups.
+template <int BMO, int BNC, int AT>
+__global__ __launch_bounds__((BMO / (16 * AT)) * (BNC / 64) * 64) void k_conv_wgrad_dma(
+    const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ dy, float* __restrict__ slab_w,
+    float* __restrict__ slab_b, ConvGeom g, int m_per_split, int nsplit, int cout) {
+    constexpr int WAVES_M = BMO / (16 * AT), WAVES_N = BNC / 64, NW = WAVES_M * WAVES_N;   // wave tile: 16*AT channels x 64 columns
+    constexpr int RB_DY = BMO * 2, RB_X = BNC * 2;             // bytes per pixel row of each tile
+    constexpr int DYI = 64 * RB_DY / 1024 / NW;                 // dY DMA instructions per wave per step
+    constexpr int XI = 64 * RB_X / 1024 / NW;
+    static_assert(DYI >= 1 && XI >= 1, "tile too small for the wave count");
+    constexpr int KM_DY = RB_DY >= 256 ? 7 : RB_DY / 32 - 1;   // permutation stays inside the row's 32-byte groups
+    constexpr int KM_X = RB_X >= 256 ? 7 : RB_X / 32 - 1;
+    constexpr int T_DY = 64 * RB_DY, T_X = 64 * RB_X;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    auto s_dy = [&](int buf) { return smem + buf * (T_DY + T_X); };
+    auto s_x = [&](int buf) { return smem + buf * (T_DY + T_X) + T_DY; };
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave % WAVES_M, wave_n = wave / WAVES_M;
+    // XCD-aware order: all (column, channel) tiles of one pixel split run consecutively on ONE XCD (L % 8), so a
+    // split's dY / X rows stream through that XCD's L2 once and are shared by its tiles.
+    const int ktot = g.ldw;
+    const int ctiles = (ktot + BNC - 1) / BNC, mtiles = (cout + BMO - 1) / BMO, tiles = ctiles * mtiles;
+    const int kx = blockIdx.x >> 3;
+    const int split = (kx / tiles) * 8 + (blockIdx.x & 7);
+    if (split >= nsplit) return;
+    const int tile = kx % tiles;
+    const int bx = tile % ctiles, by = tile / ctiles;
+    const int col0 = bx * BNC, co0 = by * BMO;
+    const int m_begin = split * m_per_split;
+    const int m_end = min(g.M, m_begin + m_per_split);
+
+    // DMA ownership.  Instruction i (= wave + NW*j) of a tile covers bytes [1024 i, 1024 i + 1024): lane L writes the
+    // 16-byte slot at o = 1024 i + 16 L -> pixel row r = o / RB, physical chunk o % RB / 16; the logical chunk it must
+    // fetch undoes the group permutation.
+    int dy_r[DYI], dy_col[DYI];
+#pragma unroll
+    for (int j = 0; j < DYI; ++j) {
+        const int o = (wave + NW * j) * 1024 + lane * 16;
+        const int r = o / RB_DY, s16 = (o % RB_DY) >> 4;
+        const int key = ((r & 3) | (((r >> 3) & 1) << 2)) & KM_DY;
+        const int gl = ((s16 >> 1) & ~KM_DY) | (((s16 >> 1) & KM_DY) ^ key);
+        dy_r[j] = r;
+        const int co = co0 + (gl * 2 + (s16 & 1)) * 8;
+        dy_col[j] = co < g.N ? co : -1;
+    }
+    // X rows: flat pixel m = mstep + x_r[j] is tracked incrementally as (image base pixel, oy, ox)
+    int x_r[XI], x_cc[XI], x_kh[XI], x_kw[XI], x_b[XI], x_oy[XI], x_ox[XI];
+#pragma unroll
+    for (int j = 0; j < XI; ++j) {
+        {
+            const int o = (wave + NW * j) * 1024 + lane * 16;
+            const int m = min(m_begin + o / RB_X, g.M - 1);
+            const int b = fdiv(m, g.d_hw);
+            const int rem = m - b * g.d_hw.d;
+            x_oy[j] = fdiv(rem, g.d_w);
+            x_ox[j] = rem - x_oy[j] * g.d_w.d;
+            x_b[j] = b * g.H * g.W;
+        }
+        const int o = (wave + NW * j) * 1024 + lane * 16;
+        const int r = o / RB_X, s16 = (o % RB_X) >> 4;
+        const int key = ((r & 3) | (((r >> 3) & 1) << 2)) & KM_X;
+        const int gl = ((s16 >> 1) & ~KM_X) | (((s16 >> 1) & KM_X) ^ key);
+        const int q = (col0 >> 3) + gl * 2 + (s16 & 1);         // global 16-byte column chunk
+        x_r[j] = r;
+        if (q < g.nchunks) {
+            const int tap = q / g.cpt;
+            x_cc[j] = q - tap * g.cpt;
+            x_kh[j] = tap / g.KW;
+            x_kw[j] = tap - x_kh[j] * g.KW;
+        } else {
+            x_cc[j] = -1; x_kh[j] = 0; x_kw[j] = 0;
+        }
+    }
+    auto issue_dma = [&](int mstep, int buf) {
+#pragma unroll
+        for (int j = 0; j < DYI; ++j) {
+            const int m = mstep + dy_r[j];
+            const bf16_raw* src = (m < m_end && dy_col[j] >= 0) ? dy + ((unsigned)m * (unsigned)g.N + (unsigned)dy_col[j])
+                                                                : reinterpret_cast<const bf16_raw*>(g_zero16);
+            if (g.ablate & 8) src = dy + ((unsigned)mstep * (unsigned)g.N + (unsigned)((wave + NW * j) * 512 + lane * 8));
+            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(s_dy(buf) + (wave + NW * j) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < XI; ++j) {
+            const int m = mstep + x_r[j];
+            const int iy = x_oy[j] * g.mul - g.pad_t + x_kh[j], ix = x_ox[j] * g.mul - g.pad_l + x_kw[j];
+            const bool ok = m < m_end && x_cc[j] >= 0 && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+            const unsigned off = (unsigned)(x_b[j] + iy * g.W + ix) * (unsigned)g.C + (unsigned)(x_cc[j] * 8);
+            const bf16_raw* src = ok ? x + off : reinterpret_cast<const bf16_raw*>(g_zero16);
+            if (g.ablate & 16) src = x + ((unsigned)mstep * (unsigned)g.C + (unsigned)((wave + NW * j) * 512 + lane * 8));
+            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(s_x(buf) + (wave + NW * j) * 1024), 16, 0, 0);
+            // advance this row by 64 output pixels for the next step
+            x_ox[j] += 64;
+            while (x_ox[j] >= g.Wo) {
+                x_ox[j] -= g.Wo;
+                if (++x_oy[j] == g.Ho) { x_oy[j] = 0; x_b[j] += g.H * g.W; }
+            }
+        }
+    };
+
+    f32x4_t acc[AT][4];
+    f32x4_t accb[AT];
+#pragma unroll
+    for (int a = 0; a < AT; ++a) {
+        accb[a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool do_bias = slab_b != nullptr && bx == 0 && wave_n == 0;
+    bf16x8_t ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+
+    const int nsteps = (m_end - m_begin + 63) / 64;
+    if (nsteps > 0) issue_dma(m_begin, 0);
+    const int gq = lane >> 4, li = lane & 15;
+    for (int st = 0; st < nsteps; ++st) {
+        const int cur = st & 1;
+        if (!(g.ablate & 2)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (st + 1 < nsteps && !(g.ablate & 1)) issue_dma(m_begin + (st + 1) * 64, cur ^ 1);
+#pragma unroll
+        for (int ksub = 0; ksub < 2; ++ksub) {
+            bf16x8_t fa[AT], fb[4];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int krow = ksub * 32 + gq * 8 + half * 4 + (li >> 2);
+                const int key = (krow & 3) | (((krow >> 3) & 1) << 2);
+#pragma unroll
+                for (int a = 0; a < AT; ++a) {
+                    const int gl = (wave_m * (16 * AT) + a * 16) >> 4;               // 32-byte group of the tile column
+                    const int gp = (gl & ~KM_DY) | ((gl & KM_DY) ^ (key & KM_DY));
+                    const char* ptr = s_dy(cur) + krow * RB_DY + gp * 32 + (li & 3) * 8;
+                    const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(ptr));
+                    reinterpret_cast<s16x4_t*>(&fa[a])[half] = v;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int gl = (wave_n * 64 + c * 16) >> 4;
+                    const int gp = (gl & ~KM_X) | ((gl & KM_X) ^ (key & KM_X));
+                    const char* ptr = s_x(cur) + krow * RB_X + gp * 32 + (li & 3) * 8;
+                    const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(ptr));
+                    reinterpret_cast<s16x4_t*>(&fb[c])[half] = v;
+                }
+            }
+            if (g.ablate & 4) {
+#pragma unroll
+                for (int a = 0; a < AT; ++a) asm volatile("" ::"v"(fa[a]));
+#pragma unroll
+                for (int c = 0; c < 4; ++c) asm volatile("" ::"v"(fb[c]));
+            } else {
+#pragma unroll
+                for (int a = 0; a < AT; ++a)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[c], acc[a][c], 0, 0, 0);
+            }
+            if (do_bias) {
+#pragma unroll
+                for (int a = 0; a < AT; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], ones, accb[a], 0, 0, 0);
+            }
+        }
+    }
+    float* out = slab_w + (long long)split * g.N * ktot;
+#pragma unroll
+    for (int a = 0; a < AT; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int col = col0 + wave_n * 64 + c * 16 + (lane & 15);
+            if (col >= ktot) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = co0 + wave_m * (16 * AT) + a * 16 + (lane >> 4) * 4 + j;
+                if (co < g.N) out[(long long)co * ktot + col] = acc[a][c][j];
+            }
+        }
+    if (do_bias && (lane & 15) == 0) {
+        float* ob = slab_b + (long long)split * g.N;
+#pragma unroll
+        for (int a = 0; a < AT; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = co0 + wave_m * (16 * AT) + a * 16 + (lane >> 4) * 4 + j;
                 if (co < g.N) ob[co] = accb[a][j];
             }
     }
@@ -697,6 +1090,9 @@ ConvGeom make_geom(int B, int H, int W, int C, int Ho, int Wo, int N, int KH, in
     g.cpt = C / 8;
     g.d_hw = make_fastdiv(Ho * Wo);
     g.d_w = make_fastdiv(Wo);
+    static int abl = -1;
+    if (abl < 0) { const char* e = getenv("SSD_ABLATE"); abl = e ? atoi(e) : 0; }
+    g.ablate = abl;
     return g;
 }
 
@@ -714,6 +1110,28 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
     const bf16_raw* xp = static_cast<const bf16_raw*>(x);
     const bf16_raw* wp = static_cast<const bf16_raw*>(w);
     const unsigned gm = (unsigned)((g.M + 127) / 128);
+    static int use_patch = -1;
+    if (use_patch < 0) { const char* e = getenv("SSD_CONV_PATCH"); use_patch = e ? atoi(e) : 128; }   // max N served
+    if (igemm_variant() >= 1 && g.KH == 3 && g.KW == 3 && g.mul == 1 && g.div == 1 && g.pad_t == 1 && g.pad_l == 1 &&
+        g.C % 64 == 0 && g.H == g.Ho && g.W == g.Wo && g.N <= use_patch && g.H >= 16 && g.W >= 16) {
+        const int tiles_x = (g.Wo + 15) / 16, tiles_y = (g.Ho + 15) / 16;
+        const int nchunk = g.C / 64;
+        const unsigned gx = (unsigned)(tiles_x * tiles_y * g.B);
+        if (g.N <= 64) {
+            const size_t lds = 3 * 64 * 128 + (nchunk > 1 ? 2 : 1) * PATCH_BYTES;
+            auto kern = k_conv3x3_patch<64, EPI>;
+            static bool set = false;
+            if (!set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 128 + 2 * PATCH_BYTES) != hipSuccess) return SSD_ERR_LAUNCH; set = true; }
+            hipLaunchKernelGGL(kern, dim3(gx, (unsigned)((g.N + 63) / 64)), dim3(512), lds, s, xp, wp, g, ep, tiles_x, tiles_y);
+        } else {
+            const size_t lds = 3 * 128 * 128 + (nchunk > 1 ? 2 : 1) * PATCH_BYTES;
+            auto kern = k_conv3x3_patch<128, EPI>;
+            static bool set = false;
+            if (!set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 128 * 128 + 2 * PATCH_BYTES) != hipSuccess) return SSD_ERR_LAUNCH; set = true; }
+            hipLaunchKernelGGL(kern, dim3(gx, (unsigned)((g.N + 127) / 128)), dim3(512), lds, s, xp, wp, g, ep, tiles_x, tiles_y);
+        }
+        return ssd_launch_status();
+    }
     if (igemm_variant() >= 1) {
         // tile choice: the CU ingests ~28 B/clk from L2, so MACs per staged byte decide the ceiling: prefer the
         // largest tile that still gives every CU work (>= ~2 workgroups per CU), SSD_CONV_TILE overrides (testing)
@@ -741,8 +1159,8 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
                     set_ = true;                                                                                   \
                 }                                                                                                  \
             }                                                                                                      \
-            hipLaunchKernelGGL(kern_, dim3((unsigned)((g.M + BM_ - 1) / BM_), (unsigned)((g.N + BN_ - 1) / BN_)),   \
-                               dim3(NT_), lds_, s, xp, wp, g, ep);                                                 \
+            const unsigned ntm_ = (unsigned)((g.M + BM_ - 1) / BM_), ntn_ = (unsigned)((g.N + BN_ - 1) / BN_);       \
+            hipLaunchKernelGGL(kern_, dim3(8 * ntn_ * ((ntm_ + 7) / 8)), dim3(NT_), lds_, s, xp, wp, g, ep);        \
         } while (0)
         if (bm == 256 && bn == 256) SSD_LAUNCH_DMA(256, 256);
         else if (bm == 256 && bn == 128) SSD_LAUNCH_DMA(256, 128);
@@ -766,6 +1184,7 @@ bool geom_ok(int B, int H, int W, int C, int Ho, int Wo, int N, int K) {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || N <= 0 || K <= 0) return false;
     if (C % 8) return false;
     if ((long long)B * Ho * Wo >= (1ll << 31) || (long long)B * H * W >= (1ll << 31)) return false;
+    if ((long long)B * H * W * C >= (1ll << 32) || (long long)B * Ho * Wo * N >= (1ll << 32)) return false;   // 32-bit element offsets
     return true;
 }
 
@@ -807,9 +1226,21 @@ int ssd_conv2d_bwd_data(const void* dy, const void* w_t, const void* relu_src, v
     return launch_igemm<EPI_DGRAD>(dy, w_t, g, ep, (hipStream_t)stream);
 }
 
+static int wgrad_dma() {                    // SSD_WGRAD_DMA=1: LDS-DMA weight-gradient kernel (default: register-staged)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("SSD_WGRAD_DMA"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
+static void wgrad_tiles(int Cout, long long ktot, int* bmo, int* bnc) {
+    *bmo = Cout > 128 ? 256 : (Cout > 64 ? 128 : 64);
+    *bnc = ktot > 128 ? 256 : 128;
+    if (!wgrad_dma()) { *bmo = 128; *bnc = 128; }
+}
+
 static int wgrad_splits(long long M, int tiles) {
-    long long want = (1024 + tiles - 1) / tiles;            // ~4 workgroups per CU in total
-    long long maxs = (M + 255) / 256;                        // at least 256 pixels per split
+    long long want = 1024 / tiles;                           // whole rounds: <= 4 workgroups per CU in total
+    long long maxs = (M + 511) / 512;                        // at least 512 pixels per split
     if (want > maxs) want = maxs;
     if (want < 1) want = 1;
     if (want > 512) want = 512;
@@ -819,7 +1250,9 @@ static int wgrad_splits(long long M, int tiles) {
 size_t ssd_conv2d_bwd_weight_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ldy, int ksize) {
     if (B <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || ldy < Cout || ksize <= 0) return 0;
     const long long ktot = (long long)ksize * ksize * Cin;
-    const int tiles = (int)(((ktot + 127) / 128) * ((Cout + 127) / 128));
+    int bmo, bnc;
+    wgrad_tiles(Cout, ktot, &bmo, &bnc);
+    const int tiles = (int)(((ktot + bnc - 1) / bnc) * ((Cout + bmo - 1) / bmo));
     const int ns = wgrad_splits((long long)B * Ho * Wo, tiles);
     return (size_t)ns * ((size_t)ldy * ktot + ldy) * sizeof(float);
 }
@@ -832,23 +1265,54 @@ int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias
     if (!ws || ws_bytes < ssd_conv2d_bwd_weight_workspace_bytes(B, Ho, Wo, Cin, Cout, ldy, ksize)) return SSD_ERR_WORKSPACE;
     ConvGeom g = make_geom(B, H, W, Cin, Ho, Wo, ldy, ksize, ksize, stride, 1, pad_t, pad_l);
     const long long ktot = g.ldw;
-    const int ctiles = (int)((ktot + 127) / 128), mtiles = (Cout + 127) / 128;
+    int bmo, bnc;
+    wgrad_tiles(Cout, ktot, &bmo, &bnc);
+    const int ctiles = (int)((ktot + bnc - 1) / bnc), mtiles = (Cout + bmo - 1) / bmo;
     const int ns = wgrad_splits(g.M, ctiles * mtiles);
     int mps = (int)(((long long)g.M + ns - 1) / ns);
     mps = (mps + 63) / 64 * 64;
     float* slab_w = static_cast<float*>(ws);
     float* slab_b = slab_w + (size_t)ns * ldy * ktot;
-    // the kernel indexes dy rows with g.N = ldy and guards co < g.N; slabs are laid out with ldy rows too
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = 4 * 64 * WG_LD;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess) return SSD_ERR_LAUNCH;
-        attr_set = true;
+    const bf16_raw* xp = static_cast<const bf16_raw*>(x);
+    const bf16_raw* dyp = static_cast<const bf16_raw*>(dy);
+    float* sb = dbias ? slab_b : nullptr;
+    if (!wgrad_dma()) {
+        const size_t lds = 4 * 64 * WG_LD;
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess) return SSD_ERR_LAUNCH;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_conv_wgrad, dim3(ctiles, mtiles, ns), dim3(WG), lds, s, xp, dyp, slab_w, sb, g, mps);
+    } else {
+#define SSD_LAUNCH_WG(BMO_, BNC_)                                                                                  \
+        do {                                                                                                       \
+            constexpr int AT_ = BMO_ >= 256 ? 8 : 4;                                                               \
+            constexpr int NT_ = (BMO_ / (16 * AT_)) * (BNC_ / 64) * 64;                                            \
+            const size_t lds_ = 2 * 64 * (BMO_ + BNC_) * 2;                                                        \
+            auto kern_ = k_conv_wgrad_dma<BMO_, BNC_, AT_>;                                                        \
+            if (lds_ > 65536) {                                                                                    \
+                static bool set_ = false;                                                                          \
+                if (!set_) {                                                                                       \
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern_),                                   \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_) != hipSuccess)   \
+                        return SSD_ERR_LAUNCH;                                                                     \
+                    set_ = true;                                                                                   \
+                }                                                                                                  \
+            }                                                                                                      \
+            hipLaunchKernelGGL(kern_, dim3(8 * ctiles * mtiles * ((ns + 7) / 8)), dim3(NT_), lds_, s, xp, dyp, slab_w, \
+                               sb, g, mps, ns, Cout);                                                              \
+        } while (0)
+        if (bmo == 256 && bnc == 256) SSD_LAUNCH_WG(256, 256);
+        else if (bmo == 128 && bnc == 256) SSD_LAUNCH_WG(128, 256);
+        else if (bmo == 64 && bnc == 256) SSD_LAUNCH_WG(64, 256);
+        else if (bmo == 256) SSD_LAUNCH_WG(256, 128);
+        else if (bmo == 128) SSD_LAUNCH_WG(128, 128);
+        else SSD_LAUNCH_WG(64, 128);
+#undef SSD_LAUNCH_WG
     }
-    hipLaunchKernelGGL(k_conv_wgrad, dim3(ctiles, mtiles, ns), dim3(WG), lds, s, static_cast<const bf16_raw*>(x),
-                       static_cast<const bf16_raw*>(dy), slab_w, dbias ? slab_b : nullptr, g, mps);
     if (hipGetLastError() != hipSuccess) return SSD_ERR_LAUNCH;
     const long long nw = (long long)Cout * ktot;             // rows >= Cout of the slab are padding channels
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, slab_w, (long long)ldy * ktot,

@@ -39,6 +39,10 @@ CASES = [
     (4, 5, 5, 128, 256, 3, 1, "valid"),      # 3x3 VALID (5 -> 3)
     (5, 3, 3, 128, 256, 3, 1, "valid"),      # 3 -> 1, M = 5
     (2, 20, 20, 8, 64, 3, 1, "same"),        # Cin = 8 (the padded image layer): taps share a k-step
+    (2, 40, 40, 128, 64, 3, 1, "same"),      # LDS-patch kernel, two channel chunks, BN = 64, partial edge tiles
+    (1, 50, 35, 128, 128, 3, 1, "same"),     # LDS-patch kernel, BN = 128, non-square, both dims partial
+    (2, 33, 33, 192, 96, 3, 1, "same"),      # LDS-patch kernel, three chunks, N not a multiple of 32
+    (1, 70, 70, 256, 320, 3, 1, "same"),     # 256-wide tiles of the LDS-DMA implicit GEMM (M = 4900, N = 320)
 ]
 
 
@@ -54,7 +58,8 @@ def geometry(ops, H, W, k, stride, mode):
 @pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
 def test_conv_fwd_bwd(ops, case):
     B, H, W, Cin, Cout, k, stride, mode = case
-    Ho, Wo, pt, pl = geometry(ops, H, W, k, stride, mode)
+    Ho, pt = geometry(ops, H, H, k, stride, mode)[0], geometry(ops, H, H, k, stride, mode)[2]
+    Wo, pl = geometry(ops, W, W, k, stride, mode)[0], geometry(ops, W, W, k, stride, mode)[2]
     g = torch.Generator().manual_seed(hash(case) % 1000)
     x = torch.randn((B, H, W, Cin), generator=g).bfloat16()
     w = (torch.randn((Cout, k, k, Cin), generator=g) / np.sqrt(k * k * Cin)).bfloat16()

@@ -46,10 +46,10 @@ def main():
     if args.gpus > 1 and world == 1:
         print("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))   # (modulo: lets a 1-GPU box rehearse N ranks)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
+        dist.init_process_group(os.environ.get("SSD_DIST_BACKEND", "nccl"))
 
     import ssd_object_detection_amd.ops as ops
     from ssd_object_detection_amd import optimizers

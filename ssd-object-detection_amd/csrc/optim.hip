@@ -41,16 +41,28 @@ __global__ __launch_bounds__(256) void k_sqnorm_partial(const float* __restrict_
     if (threadIdx.x == 0) partial[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
 }
 
-// scale[t] = clip / max(||g_t||, clip), one thread per tensor, blocks summed in order
-__global__ void k_clip_scale(const double* __restrict__ partial, const int* __restrict__ tensor_block_off, int ntensors,
-                             float clip, float* __restrict__ scale, float* __restrict__ norms) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+// scale[t] = clip / max(||g_t||, clip): one workgroup per tensor; every thread sums a strided subset of the
+// tensor's block partials in index order, then a fixed-shape tree combines them (deterministic).
+__global__ __launch_bounds__(256) void k_clip_scale(const double* __restrict__ partial, const int* __restrict__ tensor_block_off,
+                                                    int ntensors, float clip, float* __restrict__ scale,
+                                                    float* __restrict__ norms) {
+    __shared__ double s_red[256];
+    const int t = blockIdx.x;
     if (t >= ntensors) return;
+    const int b0 = tensor_block_off[t], b1 = tensor_block_off[t + 1];
     double s = 0.0;
-    for (int b = tensor_block_off[t]; b < tensor_block_off[t + 1]; ++b) s += partial[b];
-    const float nrm = (float)sqrt(s);
-    if (norms) norms[t] = nrm;
-    scale[t] = clip > 0.f ? clip / fmaxf(nrm, clip) : 1.f;
+    for (int b = b0 + threadIdx.x; b < b1; b += 256) s += partial[b];
+    s_red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) s_red[threadIdx.x] += s_red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float nrm = (float)sqrt(s_red[0]);
+        if (norms) norms[t] = nrm;
+        scale[t] = clip > 0.f ? clip / fmaxf(nrm, clip) : 1.f;
+    }
 }
 
 // g *= scale[tensor(block)]   (in place; used before the data-parallel all-reduce)
@@ -136,7 +148,7 @@ int ssd_grad_clip_scales(const float* grad, long long n, const int32_t* tensor_b
     const unsigned nb = (unsigned)(n / OPT_BLOCK);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_sqnorm_partial, dim3(nb), dim3(256), 0, s, grad, n, partial);
-    hipLaunchKernelGGL(k_clip_scale, dim3((ntensors + 63) / 64), dim3(64), 0, s, partial, tensor_block_off, ntensors, clip,
+    hipLaunchKernelGGL(k_clip_scale, dim3(ntensors), dim3(256), 0, s, partial, tensor_block_off, ntensors, clip,
                        scale, norms);
     return ssd_launch_status();
 }

@@ -46,8 +46,8 @@ IMAGE_CHANNELS = 3
 
 
 class ParamTensor:
-    def __init__(self, name, shape, offset):
-        self.name, self.shape, self.offset = name, tuple(shape), offset
+    def __init__(self, name, shape, offset, index):
+        self.name, self.shape, self.offset, self.index = name, tuple(shape), offset, index
         self.numel = int(np.prod(shape))
 
 
@@ -94,7 +94,7 @@ class SSDEngine:
 
         def add(name, shape):
             nonlocal off
-            t = ParamTensor(name, shape, off)
+            t = ParamTensor(name, shape, off, len(self.tensors))
             self.tensors.append(t)
             off += (t.numel + self.block - 1) // self.block * self.block
             return t
@@ -226,8 +226,9 @@ class SSDEngine:
                                 c["conf"], self.num_priors[lvl], self.classes, self.level_off[lvl])
         return c["loc"], c["conf"]
 
-    def backward(self, dloc, dconf):
-        """Gradients of all parameters into self.grad (flat fp32) from d(loss)/d(loc), d(loss)/d(conf)."""
+    def backward(self, dloc, dconf, on_ready=None):
+        """Gradients of all parameters into self.grad (flat fp32) from d(loss)/d(loc), d(loss)/d(conf).
+        on_ready([tensor indices]) is called right after the launches that complete those tensors' gradients."""
         B = dloc.shape[0]
         c = self._acts(B)
         acts, gacts = c["acts"], c["gacts"]
@@ -240,6 +241,8 @@ class SSDEngine:
             wt, bt = self.head_params[lvl]
             ops.conv2d_bwd_weight(acts[ni + 1], packed, wt.shape[0], 3, 1, 1, 1, dw=self.view(wt, self.grad),
                                   dbias=self.view(bt, self.grad), ws=self._ws)
+            if on_ready:
+                on_ready([wt.index, bt.index])
             ops.conv2d_bwd_data(packed, self.head_w_t[lvl], acts[ni + 1], acts[ni + 1].shape, 1, 1, 1,
                                 accumulate=False, out=gacts[ni + 1])
             written[ni + 1] = True
@@ -255,6 +258,8 @@ class SSDEngine:
             wt, bt = self.conv_params[i]
             ops.conv2d_bwd_weight(acts[i], g_out, nd["cout"], nd["k"], nd["stride"], nd["pt"], nd["pl"],
                                   dw=self.view(wt, self.grad), dbias=self.view(bt, self.grad), ws=self._ws)
+            if on_ready:
+                on_ready([wt.index, bt.index])
             if i == 0:
                 continue                          # no gradient w.r.t. the image
             prev_is_relu_conv = self.nodes[i - 1]["kind"] == "conv"
@@ -272,6 +277,27 @@ class SSDEngine:
     def apply_clip_in_place(self):
         _lib.check(self.L.ssd_grad_apply_scale(ops._ptr(self.grad), self.n_flat, ops._ptr(self.block_tensor),
                                                ops._ptr(self.clip_scale), ops._stream()))
+
+    def clip_range_in_place(self, t0, t1, clip=0.01):
+        """clip_by_norm of tensors t0..t1-1 (a contiguous range of the flat gradient) in place, on the current stream."""
+        key = (t0, t1)
+        if not hasattr(self, "_range_tables"):
+            self._range_tables = {}
+        tab = self._range_tables.get(key)
+        if tab is None:
+            b0 = self.tensors[t0].offset // self.block
+            tbo = (self.tensor_block_off[t0:t1 + 1] - b0).contiguous()
+            bt = (self.block_tensor[b0:int(self.tensor_block_off[t1].item())] - t0).contiguous()
+            tab = (b0, tbo, bt)
+            self._range_tables[key] = tab
+        b0, tbo, bt = tab
+        start = b0 * self.block
+        n = bt.numel() * self.block
+        g = self.grad[start:start + n]
+        _lib.check(self.L.ssd_grad_clip_scales(ops._ptr(g), n, ops._ptr(tbo), t1 - t0, float(clip),
+                                               ops._ptr(self.sq_partial[b0:]), ops._ptr(self.clip_scale[t0:]),
+                                               ops._ptr(self.grad_norms[t0:]), ops._stream()))
+        _lib.check(self.L.ssd_grad_apply_scale(ops._ptr(g), n, ops._ptr(bt), ops._ptr(self.clip_scale[t0:]), ops._stream()))
 
     def accumulate_clipped(self, first):
         if self.grad_acc is None:

@@ -20,6 +20,7 @@ import torch
 
 from .. import ops
 from ..engine import SSDEngine
+from ..parallel import GradReducer
 from .. import optimizers as _opt
 
 logger = logging.getLogger(__name__)
@@ -60,6 +61,7 @@ class SSDObjectDetectionModel:
         self._prior_box = None
         self._comm_stream = None
         self._slot_owner = None                      # optimizer object whose Adam moments the engine holds
+        self._reducer = None
         self.last_info = None
 
     # ------------------------------------------------------------------ accessors
@@ -124,15 +126,25 @@ class SSDObjectDetectionModel:
         info = None
         world = torch.distributed.get_world_size() if self.distributed else 1
         single = world == 1 and batch_step >= batch_size
+        overlap = world > 1 and batch_step >= batch_size           # one micro-batch per rank: bucketed, overlapped reduce
+        if overlap and self._reducer is None:
+            blocks = [(t.numel + eng.block - 1) // eng.block for t in eng.tensors]
+            self._reducer = GradReducer(eng.grad, [t.offset for t in eng.tensors], blocks, eng.block,
+                                        eng.clip_range_in_place)
         for i in range(0, batch_size, batch_step):
             x = ops.image_prep(image[i:i + batch_step].contiguous(), normalize=False)
             pred_loc, pred_conf = eng.forward(x)
             _, info = self._ssd_loss((gt_cls[i:i + batch_step], gt_bbox[i:i + batch_step], gt_mask[i:i + batch_step]),
                                      (pred_loc, pred_conf))
-            eng.backward(info["dloc"], info["dconf"])
-            eng.clip_scales(0.01)                      # tf.clip_by_norm(x, 0.01) per tensor, reference :249
-            if not single:
-                eng.accumulate_clipped(first=(n_micro == 0))
+            if overlap:
+                self._reducer.begin()
+                eng.backward(info["dloc"], info["dconf"], on_ready=self._reducer.tensor_ready)
+                self._reducer.finish()                 # clipped per bucket, summed over ranks (RCCL over xGMI)
+            else:
+                eng.backward(info["dloc"], info["dconf"])
+                eng.clip_scales(0.01)                  # tf.clip_by_norm(x, 0.01) per tensor, reference :249
+                if not single:
+                    eng.accumulate_clipped(first=(n_micro == 0))
             n_micro += 1
         if self._slot_owner is not ssd_optimizer:     # Keras keeps separate slots per optimizer (warm-up vs train)
             eng.adam_m.zero_()
@@ -141,6 +153,8 @@ class SSDObjectDetectionModel:
         lr = ssd_optimizer.lr()
         if single:
             grad, gscale, use_clip = eng.grad, 1.0, True
+        elif overlap:
+            grad, gscale, use_clip = eng.grad, 1.0 / world, False
         else:
             grad, use_clip = eng.grad_acc, False
             if world > 1:

@@ -1,0 +1,100 @@
+"""Data-parallel gradient exchange: image-sharded DP with ONE logical all-reduce per step, issued as a few large
+buckets that overlap the rest of the backward pass.
+
+Semantics: every rank is one micro-batch of the reference's split_batch loop
+(models/ssd_model.py:240-256 of the reference): gradients are clipped per tensor on the rank that produced them
+(tf.clip_by_norm, :249), summed over ranks (all-reduce) and divided by the rank count (:256, folded into the
+optimizer kernel's grad_scale).
+
+The flat gradient buffer is laid out in forward order and the backward pass completes it from the back (heads,
+then conv22 ... conv0), so buckets are contiguous ranges taken from the end of the buffer.  As soon as the last
+tensor of a bucket has its weight gradient enqueued, the bucket is clipped in place and all-reduced on a side
+stream while the compute stream keeps running the (FLOP-heavy, parameter-light) VGG layers.  xGMI is point to
+point (7 links x ~153 GB/s per GPU): few, large messages; the default 4 buckets of ~25 MB each.
+"""
+import torch
+import torch.distributed as dist
+
+
+def make_buckets(sizes_blocks, target_blocks):
+    """Partition tensors 0..n-1 (sizes in optimizer blocks, flat order) into contiguous buckets filled from the
+    END of the buffer.  Returns a list of (first_tensor, last_tensor_exclusive) in completion order."""
+    buckets = []
+    hi = len(sizes_blocks)
+    acc = 0
+    end = hi
+    for t in range(hi - 1, -1, -1):
+        acc += sizes_blocks[t]
+        if acc >= target_blocks or t == 0:
+            buckets.append((t, end))
+            end = t
+            acc = 0
+    return buckets
+
+
+class GradReducer:
+    """Bucketed, overlapped sum-all-reduce of a flat gradient tensor.
+
+    clip_fn(t0, t1) must clip tensors t0..t1-1 of the flat buffer in place (on the current stream / synchronously on
+    CPU); it is how the engine's HIP kernels are plugged in, and how CPU tests plug in a numpy reference."""
+
+    def __init__(self, flat_grad, tensor_offsets, tensor_blocks, block_elems, clip_fn, n_buckets=4, group=None):
+        self.flat = flat_grad
+        self.offsets = list(tensor_offsets)
+        self.blocks = list(tensor_blocks)
+        self.block_elems = block_elems
+        self.clip_fn = clip_fn
+        self.group = group
+        total = sum(self.blocks)
+        self.buckets = make_buckets(self.blocks, max(1, (total + n_buckets - 1) // n_buckets))
+        self.use_streams = flat_grad.is_cuda
+        self.comm = torch.cuda.Stream() if self.use_streams else None
+        self.begin()
+
+    def begin(self):
+        self.ready = [False] * len(self.offsets)
+        self.next_bucket = 0
+        self.handles = []
+
+    def _range(self, t0, t1):
+        start = self.offsets[t0]
+        end = self.offsets[t1 - 1] + self.blocks[t1 - 1] * self.block_elems
+        return start, end
+
+    def tensor_ready(self, idxs):
+        for i in idxs:
+            self.ready[i] = True
+        while self.next_bucket < len(self.buckets):
+            t0, t1 = self.buckets[self.next_bucket]
+            if not all(self.ready[t0:t1]):
+                break
+            self._launch(t0, t1)
+            self.next_bucket += 1
+
+    def _launch(self, t0, t1):
+        start, end = self._range(t0, t1)
+        view = self.flat[start:end]
+        if self.use_streams:
+            ev = torch.cuda.Event()
+            ev.record()                                   # the bucket's weight gradients are enqueued
+            with torch.cuda.stream(self.comm):
+                self.comm.wait_event(ev)
+                self.clip_fn(t0, t1)
+                self.handles.append(dist.all_reduce(view, group=self.group, async_op=True))
+        else:
+            self.clip_fn(t0, t1)
+            self.handles.append(dist.all_reduce(view, group=self.group, async_op=True))
+
+    def finish(self):
+        assert self.next_bucket == len(self.buckets), "backward did not report every tensor"
+        for h in self.handles:
+            h.wait()
+        if self.use_streams:
+            torch.cuda.current_stream().wait_stream(self.comm)
+        self.handles = []
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous shard [lo, hi) of n_items for `rank` (image sharding of a global batch)."""
+    per = n_items // world
+    return rank * per, (rank + 1) * per

@@ -38,7 +38,7 @@ def train(config):
     distributed = int(os.environ.get("WORLD_SIZE", "1")) > 1
     if distributed:
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        torch.distributed.init_process_group("nccl")
+        torch.distributed.init_process_group(os.environ.get("SSD_DIST_BACKEND", "nccl"))
     data = SSDDataLoader(dataset_root=config["data"]["dataset_root"], shuffle=config["data"]["shuffle"],
                          dataset=config["data"]["dataset"],
                          mini_batch=config["data"]["mini_batch"]["num_data"] if config["data"]["mini_batch"]["enable"] else 0)

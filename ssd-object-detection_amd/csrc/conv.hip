@@ -941,6 +941,159 @@ __global__ __launch_bounds__((BMO / (16 * AT)) * (BNC / 64) * 64) void k_conv_wg
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of a 3x3 / stride 1 / pad 1 convolution with LDS-resident tiles ("patch" form).
+// A workgroup owns 64 output channels x 64 input channels (one channel chunk) x all nine taps, and walks a range
+// of 16x16 output-pixel blocks.  Per block it brings in the dY tile [256 px][64 co] and the 18x18 halo patch of X
+// [324 px][64 ci] ONCE (LDS-DMA, double-buffered); wave t (of nine) accumulates tap t:
+//     dW[co][t][ci] += sum_px dY[px][co] * X[px + shift(t)][ci]
+// with both operands fetched by transposing LDS reads (the patch at tap-shifted addresses).  ~128 MACs per byte
+// brought into the CU, versus 32 for the generic 128x128 tile that re-stages X for every tap.
+constexpr int WP_DY_BYTES = 256 * 128;                     // 32 KiB
+constexpr int WP_BUF = WP_DY_BYTES + PATCH_BYTES;          // one buffer: dY tile + X patch
+
+// 32-byte column group permutation of a 128-byte pixel row: conflict-free for the 4+4 rows of a half-wave
+__device__ __forceinline__ int wp_key(int px) { return (px & 3) ^ (((px >> 3) & 1) << 1); }
+
+__global__ __launch_bounds__(576) void k_conv3x3_wgrad_patch(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ dy,
+                                                             float* __restrict__ slab_w, float* __restrict__ slab_b,
+                                                             ConvGeom g, int tiles_x, int tiles_y, int tiles_per_split,
+                                                             int nsplit, int cout) {
+    // g: source = x (B,H,W,C), destination = dy (Ho=H, Wo=W, N = ldy)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    auto s_dy = [&](int buf) { return smem + buf * WP_BUF; };
+    auto s_px = [&](int buf) { return smem + buf * WP_BUF + WP_DY_BYTES; };
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0..8 = tap
+    const int kh = wave / 3, kw = wave - 3 * kh;
+    const int nchunk = g.C >> 6, cotiles = (cout + 63) >> 6;
+    int id = blockIdx.x;
+    const int chunk = id % nchunk; id /= nchunk;
+    const int cot = id % cotiles;
+    const int split = id / cotiles;
+    const int co0 = cot * 64, ci0 = chunk * 64;
+    const int ntiles = g.B * tiles_x * tiles_y;
+    const int t_begin = split * tiles_per_split, t_end = min(ntiles, t_begin + tiles_per_split);
+
+    // DMA ownership: dY tile = 32 instructions, patch = 41; instruction i of each goes to wave i % 9
+    auto issue_dma = [&](int t, int buf) {
+        int r = t;
+        const int tx = r % tiles_x; r /= tiles_x;
+        const int ty = r % tiles_y;
+        const int b = r / tiles_y;
+        const int y0 = ty * 16, x0 = tx * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = wave + 9 * j;
+            if (i < 32) {                                   // 8 pixels x 128 B per instruction
+                const int px = 8 * i + (lane >> 3), sl = lane & 7;
+                const int c16 = (((sl >> 1) ^ wp_key(px)) << 1) | (sl & 1);
+                const int y = y0 + (px >> 4), xx = x0 + (px & 15);
+                const int co = co0 + c16 * 8;
+                const bool ok = y < g.Ho && xx < g.Wo && co < g.N;
+                const bf16_raw* src = ok ? dy + ((unsigned)((b * g.Ho + y) * g.Wo + xx) * (unsigned)g.N + (unsigned)co)
+                                         : reinterpret_cast<const bf16_raw*>(g_zero16);
+                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(s_dy(buf) + i * 1024), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int i = wave + 9 * j;
+            if (i < PATCH_INSTR) {
+                const int pp = 8 * i + (lane >> 3), sl = lane & 7;
+                const int c16 = (((sl >> 1) ^ wp_key(pp)) << 1) | (sl & 1);
+                const int py = pp / PATCH_W, px = pp - py * PATCH_W;
+                const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+                const bool ok = pp < PATCH_PIX && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+                const bf16_raw* src = ok ? x + ((unsigned)((b * g.H + iy) * g.W + ix) * (unsigned)g.C + (unsigned)(ci0 + c16 * 8))
+                                         : reinterpret_cast<const bf16_raw*>(g_zero16);
+                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(s_px(buf) + i * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x4_t acc[4][4];
+    f32x4_t accb[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        accb[a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool do_bias = slab_b != nullptr && chunk == 0 && wave == 4;
+    bf16x8_t ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+
+    if (t_begin < t_end) issue_dma(t_begin, 0);
+    const int gq = lane >> 4, li = lane & 15;
+    for (int t = t_begin; t < t_end; ++t) {
+        const int cur = (t - t_begin) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < t_end) issue_dma(t + 1, cur ^ 1);
+        const char* pdy = s_dy(cur);
+        const char* ppx = s_px(cur);
+#pragma unroll 2
+        for (int ks = 0; ks < 8; ++ks) {                    // 32 pixels (two block rows) per k-step
+            bf16x8_t fa[4], fb[4];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int kk = ks * 32 + gq * 8 + half * 4 + (li >> 2);      // pixel of the block = MFMA k index
+                const int ka = wp_key(kk);
+                const int pp = ((kk >> 4) + kh) * PATCH_W + (kk & 15) + kw;  // tap-shifted patch pixel
+                const int kb = wp_key(pp);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const char* ptr = pdy + kk * 128 + ((a ^ ka) << 5) + (li & 3) * 8;
+                    reinterpret_cast<s16x4_t*>(&fa[a])[half] =
+                        __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(ptr));
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const char* ptr = ppx + pp * 128 + ((c ^ kb) << 5) + (li & 3) * 8;
+                    reinterpret_cast<s16x4_t*>(&fb[c])[half] =
+                        __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(ptr));
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[c], acc[a][c], 0, 0, 0);
+            if (do_bias) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], ones, accb[a], 0, 0, 0);
+            }
+        }
+    }
+    // slab[split][co][tap][ci]  (dW layout [Cout][kh][kw][Cin], rows = ldy channels)
+    const int ktot = g.ldw;
+    float* out = slab_w + (long long)split * g.N * ktot;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int col = wave * g.C + ci0 + c * 16 + (lane & 15);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = co0 + a * 16 + (lane >> 4) * 4 + j;
+                if (co < g.N) out[(long long)co * ktot + col] = acc[a][c][j];
+            }
+        }
+    if (do_bias && (lane & 15) == 0) {
+        float* ob = slab_b + (long long)split * g.N;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = co0 + a * 16 + (lane >> 4) * 4 + j;
+                if (co < g.N) ob[co] = accb[a][j];
+            }
+    }
+}
+
 // dW[i] = sum_z slab[z][i] in fixed order; also the bias gradient.
 __global__ void k_wgrad_reduce(const float* __restrict__ slab, long long n, int nsplit, float* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1232,6 +1385,29 @@ static int wgrad_dma() {                    // SSD_WGRAD_DMA=1: LDS-DMA weight-g
     return v;
 }
 
+static int wgrad_patch_min_hw() {           // SSD_WGRAD_PATCH = smallest feature-map side served by the patch kernel (0: off)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("SSD_WGRAD_PATCH"); v = e ? atoi(e) : 32; }
+    return v;
+}
+
+static bool wgrad_use_patch(int H, int W, int Ho, int Wo, int Cin, int ksize, int stride, int pad_t, int pad_l) {
+    const int mn = wgrad_patch_min_hw();
+    return mn > 0 && ksize == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && H == Ho && W == Wo && Cin % 64 == 0 &&
+           H >= mn && W >= mn;
+}
+
+static void wgrad_patch_plan(int B, int Ho, int Wo, int Cin, int Cout, int* tiles_x, int* tiles_y, int* tps, int* ns) {
+    *tiles_x = (Wo + 15) / 16; *tiles_y = (Ho + 15) / 16;
+    const int ntiles = B * *tiles_x * *tiles_y;
+    const int groups = (Cin / 64) * ((Cout + 63) / 64);
+    int want = 512 / groups;                                 // ~2 rounds of one workgroup per CU
+    if (want < 1) want = 1;
+    if (want > ntiles) want = ntiles;
+    *tps = (ntiles + want - 1) / want;
+    *ns = (ntiles + *tps - 1) / *tps;
+}
+
 static void wgrad_tiles(int Cout, long long ktot, int* bmo, int* bnc) {
     *bmo = Cout > 128 ? 256 : (Cout > 64 ? 128 : 64);
     *bnc = ktot > 128 ? 256 : 128;
@@ -1250,11 +1426,18 @@ static int wgrad_splits(long long M, int tiles) {
 size_t ssd_conv2d_bwd_weight_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ldy, int ksize) {
     if (B <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || ldy < Cout || ksize <= 0) return 0;
     const long long ktot = (long long)ksize * ksize * Cin;
+    size_t patch_bytes = 0;
+    if (wgrad_use_patch(Ho, Wo, Ho, Wo, Cin, ksize, 1, 1, 1)) {     // upper bound if the call turns out to be a patch case
+        int tx, ty, tps, ns;
+        wgrad_patch_plan(B, Ho, Wo, Cin, Cout, &tx, &ty, &tps, &ns);
+        patch_bytes = (size_t)ns * ((size_t)ldy * ktot + ldy) * sizeof(float);
+    }
     int bmo, bnc;
     wgrad_tiles(Cout, ktot, &bmo, &bnc);
     const int tiles = (int)(((ktot + bnc - 1) / bnc) * ((Cout + bmo - 1) / bmo));
     const int ns = wgrad_splits((long long)B * Ho * Wo, tiles);
-    return (size_t)ns * ((size_t)ldy * ktot + ldy) * sizeof(float);
+    const size_t gen = (size_t)ns * ((size_t)ldy * ktot + ldy) * sizeof(float);
+    return gen > patch_bytes ? gen : patch_bytes;
 }
 
 int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias, int B, int H, int W, int Cin, int Cout,
@@ -1265,6 +1448,30 @@ int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias
     if (!ws || ws_bytes < ssd_conv2d_bwd_weight_workspace_bytes(B, Ho, Wo, Cin, Cout, ldy, ksize)) return SSD_ERR_WORKSPACE;
     ConvGeom g = make_geom(B, H, W, Cin, Ho, Wo, ldy, ksize, ksize, stride, 1, pad_t, pad_l);
     const long long ktot = g.ldw;
+    if (wgrad_use_patch(H, W, Ho, Wo, Cin, ksize, stride, pad_t, pad_l)) {
+        int tx, ty, tps, ns;
+        wgrad_patch_plan(B, Ho, Wo, Cin, Cout, &tx, &ty, &tps, &ns);
+        float* slab_w = static_cast<float*>(ws);
+        float* slab_b = slab_w + (size_t)ns * ldy * ktot;
+        hipStream_t s = (hipStream_t)stream;
+        const size_t lds = 2 * WP_BUF;
+        static bool set = false;
+        if (!set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_wgrad_patch), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess) return SSD_ERR_LAUNCH;
+            set = true;
+        }
+        const unsigned grid = (unsigned)((Cin / 64) * ((Cout + 63) / 64) * ns);
+        hipLaunchKernelGGL(k_conv3x3_wgrad_patch, dim3(grid), dim3(576), lds, s, static_cast<const bf16_raw*>(x),
+                           static_cast<const bf16_raw*>(dy), slab_w, dbias ? slab_b : nullptr, g, tx, ty, tps, ns, Cout);
+        if (hipGetLastError() != hipSuccess) return SSD_ERR_LAUNCH;
+        const long long nw = (long long)Cout * ktot;
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, slab_w, (long long)ldy * ktot,
+                           ns, dw);
+        if (dbias) hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((Cout + 255) / 256)), dim3(256), 0, s, slab_b,
+                                      (long long)ldy, ns, dbias);
+        return ssd_launch_status();
+    }
     int bmo, bnc;
     wgrad_tiles(Cout, ktot, &bmo, &bnc);
     const int ctiles = (int)((ktot + bnc - 1) / bnc), mtiles = (Cout + bmo - 1) / bmo;

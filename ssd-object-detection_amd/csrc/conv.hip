@@ -68,10 +68,18 @@ struct ConvGeom {
     int ldw;                                 // weight row stride (elements) = KH*KW*C
     int cpt;                                 // chunks per tap = C/8
     FastDiv d_hw, d_w;                       // divide by Ho*Wo and by Wo
+    // stride-2 data gradient: destination pixels are enumerated parity class by parity class (py,px), each class
+    // padded to whole tiles, so that a tile has ONE parity and the taps that cannot hit it are skipped outright
+    int s2;                                  // 1: parity-class enumeration active (div == 2, cpt % 8 == 0)
+    int cls_n[4];                            // pixels per class (B * cls_h[py] * cls_w[px]), class = 2*py + px
+    int cls_h[2], cls_w[2];
     int ablate;                              // dev only (SSD_ABLATE): 1 no DMA after the prologue, 2 no wait/barrier, 4 no MFMA
 };
 
 enum { EPI_FWD = 0, EPI_HEAD = 1, EPI_DGRAD = 2 };
+#ifndef SSD_PT256
+#define SSD_PT256 4                           // pixel tiles per wave of the 256x256 implicit-GEMM tile (8 = 8 waves of 128x64: no faster)
+#endif
 
 struct Epilogue {
     const float* bias;                       // [N] or null                       (FWD, HEAD)
@@ -326,14 +334,13 @@ __device__ __attribute__((aligned(16))) const unsigned g_zero16[4] = {0u, 0u, 0u
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
 
-template <int BM, int BN, int EPI>
-__global__ __launch_bounds__((BM / 64) * (BN >= 128 ? BN / 64 : 2) * 64) void k_conv_igemm_dma(
+template <int BM, int BN, int EPI, int PT>
+__global__ __launch_bounds__((BM / (16 * PT)) * (BN >= 128 ? BN / 64 : 2) * 64) void k_conv_igemm_dma(
     const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ w, ConvGeom g, Epilogue ep) {
-    constexpr int WAVES_M = BM / 64;
+    constexpr int WAVES_M = BM / (16 * PT);     // wave tile: 16*PT pixels x 16*CT channels
     constexpr int WAVES_N = BN >= 128 ? BN / 64 : 2;
     constexpr int NW = WAVES_M * WAVES_N;       // waves per workgroup (4, 8 or 16)
     constexpr int CT = BN / (16 * WAVES_N);     // 16-wide channel tiles per wave (4, or 2 for BN = 64)
-    constexpr int PT = 4;                       // 16-wide pixel tiles per wave
     constexpr int XI = BM / 8 / NW;             // activation DMA instructions per wave per k-step
     constexpr int WI = BN / 8 / NW;             // weight DMA instructions per wave per k-step
     static_assert(XI >= 1 && WI >= 1, "tile too small for the wave count");
@@ -346,11 +353,44 @@ __global__ __launch_bounds__((BM / 64) * (BN >= 128 ? BN / 64 : 2) * 64) void k_
     const int wave_m = wave % WAVES_M, wave_n = wave / WAVES_M;
     // XCD-aware tile order: workgroup L runs on XCD L % 8 (round-robin dispatch); the N-tiles of one pixel tile are
     // consecutive on ONE XCD so that the gathered activation tile is fetched into that XCD's L2 once.
-    const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
+    const int ntn = (g.N + BN - 1) / BN;
+    int ntm = (g.M + BM - 1) / BM;
+    if (g.s2) ntm = (g.cls_n[0] + BM - 1) / BM + (g.cls_n[1] + BM - 1) / BM + (g.cls_n[2] + BM - 1) / BM + (g.cls_n[3] + BM - 1) / BM;
     const int kx = blockIdx.x >> 3;
     const int mt = (kx / ntn) * 8 + (blockIdx.x & 7);
     if (mt >= ntm) return;
-    const int m0 = mt * BM, n0 = (kx % ntn) * BN;
+    int m0 = mt * BM;
+    const int n0 = (kx % ntn) * BN;
+    // parity class of this tile (stride-2 data gradient only)
+    int cls = 0, cls_count = g.M, cls_py = 0, cls_px = 0, cls_hw = 1, cls_wd = 1;
+    if (g.s2) {
+        int t0 = 0;
+        for (cls = 0; cls < 3; ++cls) {
+            const int ntc = (g.cls_n[cls] + BM - 1) / BM;
+            if (mt < t0 + ntc) break;
+            t0 += ntc;
+        }
+        m0 = (mt - t0) * BM;
+        cls_count = g.cls_n[cls];
+        cls_py = cls >> 1; cls_px = cls & 1;
+        cls_wd = g.cls_w[cls_px];
+        cls_hw = g.cls_h[cls_py] * cls_wd;
+    }
+    // destination pixel (b, oy, ox) of tile-local row index m (class-local when s2)
+    auto decode = [&](int m, int& bb, int& oy, int& ox) {
+        if (g.s2) {
+            bb = m / cls_hw;
+            const int rem = m - bb * cls_hw;
+            const int a = rem / cls_wd;
+            oy = 2 * a + cls_py;
+            ox = 2 * (rem - a * cls_wd) + cls_px;
+        } else {
+            bb = fdiv(m, g.d_hw);
+            const int rem = m - bb * g.d_hw.d;
+            oy = fdiv(rem, g.d_w);
+            ox = rem - oy * g.d_w.d;
+        }
+    };
 
     // DMA ownership: wave-instruction i = (wave&1) + 2*((wave>>1) + (NW/2)*j) covers tile rows 8i..8i+7 (i has the
     // wave's parity, so a lane fetches the same k-chunk for all of its rows);
@@ -364,12 +404,9 @@ __global__ __launch_bounds__((BM / 64) * (BN >= 128 ? BN / 64 : 2) * 64) void k_
     for (int j = 0; j < XI; ++j) {
         const int i = (wave & 1) + 2 * ((wave >> 1) + (NW / 2) * j);
         const int m = m0 + 8 * i + rl;
-        const bool mv = m < g.M;
-        const int mm = mv ? m : 0;
-        const int b = fdiv(mm, g.d_hw);
-        const int rem = mm - b * g.d_hw.d;
-        const int oy = fdiv(rem, g.d_w);
-        const int ox = rem - oy * g.d_w.d;
+        const bool mv = m < cls_count;
+        int b, oy, ox;
+        decode(mv ? m : 0, b, oy, ox);
         ybase[j] = mv ? oy * g.mul - g.pad_t : -(1 << 20);
         xbase[j] = ox * g.mul - g.pad_l;
         ibase[j] = b * g.H * g.W;              // < 2^31 (checked on the host)
@@ -420,8 +457,27 @@ __global__ __launch_bounds__((BM / 64) * (BN >= 128 ? BN / 64 : 2) * 64) void k_
 #pragma unroll
         for (int p = 0; p < PT; ++p) acc[c][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int nks = (g.nchunks + 7) >> 3;
-    issue_dma(0);
+    int nks = (g.nchunks + 7) >> 3;
+    // stride-2 data gradient: only the taps whose parity matches the tile's class contribute; steps are addressed
+    // absolutely as (valid tap vt, sub-step) instead of incrementally
+    int vtaps = 0, nvt = 0;                     // 4 bits per valid tap index
+    const int spt = g.cpt >> 3;                 // k-steps per tap (s2 only)
+    if (g.s2) {
+        for (int t = 0; t < g.KH * g.KW; ++t) {
+            const int th = t / g.KW, tw = t - th * g.KW;
+            if ((((cls_py - g.pad_t + th) | (cls_px - g.pad_l + tw)) & 1) == 0) { vtaps |= t << (4 * nvt); ++nvt; }
+        }
+        nks = nvt * spt;
+    }
+    auto set_step = [&](int step) {             // s2: position the k state on valid step `step`
+        const int vt = step / spt, sub = step - vt * spt;
+        const int t = (vtaps >> (4 * vt)) & 15;
+        kh = t / g.KW; kw = t - kh * g.KW;
+        cc = sub * 8 + slot;
+        q = t * g.cpt + cc;
+    };
+    if (g.s2 && nks > 0) set_step(0);
+    if (nks > 0) issue_dma(0);
     const int frow = lane & 15, fk = lane >> 4;
     for (int ks = 0; ks < nks; ++ks) {
         const int cur = ks & 1;
@@ -429,13 +485,16 @@ __global__ __launch_bounds__((BM / 64) * (BN >= 128 ? BN / 64 : 2) * 64) void k_
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
-        if (ks + 1 < nks && !(g.ablate & 1)) issue_dma(cur ^ 1);
+        if (ks + 1 < nks && !(g.ablate & 1)) {
+            if (g.s2) set_step(ks + 1);
+            issue_dma(cur ^ 1);
+        }
 #pragma unroll
         for (int ksub = 0; ksub < 2; ++ksub) {
             bf16x8_t fx[PT], fw[CT];
 #pragma unroll
             for (int p = 0; p < PT; ++p)
-                fx[p] = *reinterpret_cast<const bf16x8_t*>(s_x(cur) + swz(wave_m * 64 + p * 16 + frow, ksub * 4 + fk));
+                fx[p] = *reinterpret_cast<const bf16x8_t*>(s_x(cur) + swz(wave_m * (16 * PT) + p * 16 + frow, ksub * 4 + fk));
 #pragma unroll
             for (int c = 0; c < CT; ++c)
                 fw[c] = *reinterpret_cast<const bf16x8_t*>(s_w(cur) + swz(wave_n * (16 * CT) + c * 16 + frow, ksub * 4 + fk));
@@ -453,7 +512,18 @@ __global__ __launch_bounds__((BM / 64) * (BN >= 128 ? BN / 64 : 2) * 64) void k_
             }
         }
     }
-    conv_epilogue<BN, EPI, CT, PT>(acc, g, ep, m0, n0, wave_m, wave_n, lane);
+    int mrow[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const int m = m0 + wave_m * (16 * PT) + p * 16 + (lane & 15);
+        mrow[p] = m < cls_count ? m : -1;
+        if (g.s2 && mrow[p] >= 0) {
+            int b, oy, ox;
+            decode(m, b, oy, ox);
+            mrow[p] = (b * g.Ho + oy) * g.Wo + ox;
+        }
+    }
+    conv_epilogue_rows<EPI, CT, PT>(acc, g, ep, mrow, n0 + wave_n * (16 * CT), lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1246,6 +1316,14 @@ ConvGeom make_geom(int B, int H, int W, int C, int Ho, int Wo, int N, int KH, in
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("SSD_ABLATE"); abl = e ? atoi(e) : 0; }
     g.ablate = abl;
+    g.s2 = 0;
+    static int s2on = -1;
+    if (s2on < 0) { const char* e = getenv("SSD_DGRAD_S2"); s2on = e ? atoi(e) : 1; }
+    if (div == 2 && s2on && g.cpt % 8 == 0) {
+        g.s2 = 1;
+        for (int p = 0; p < 2; ++p) { g.cls_h[p] = (Ho + 1 - p) / 2; g.cls_w[p] = (Wo + 1 - p) / 2; }
+        for (int c = 0; c < 4; ++c) g.cls_n[c] = B * g.cls_h[c >> 1] * g.cls_w[c & 1];
+    }
     return g;
 }
 
@@ -1300,9 +1378,10 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
         (void)wg_128;
 #define SSD_LAUNCH_DMA(BM_, BN_)                                                                                   \
         do {                                                                                                       \
-            constexpr int NT_ = (BM_ / 64) * (BN_ >= 128 ? BN_ / 64 : 2) * 64;                                      \
+            constexpr int PT_ = (BM_ == 256 && BN_ == 256) ? SSD_PT256 : 4;                                         \
+            constexpr int NT_ = (BM_ / (16 * PT_)) * (BN_ >= 128 ? BN_ / 64 : 2) * 64;                              \
             const size_t lds_ = 2 * (BM_ + BN_) * 128;                                                             \
-            auto kern_ = k_conv_igemm_dma<BM_, BN_, EPI>;                                                          \
+            auto kern_ = k_conv_igemm_dma<BM_, BN_, EPI, PT_>;                                                     \
             if (lds_ > 65536) {                                                                                    \
                 static bool set_ = false;                                                                          \
                 if (!set_) {                                                                                       \
@@ -1312,7 +1391,9 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
                     set_ = true;                                                                                   \
                 }                                                                                                  \
             }                                                                                                      \
-            const unsigned ntm_ = (unsigned)((g.M + BM_ - 1) / BM_), ntn_ = (unsigned)((g.N + BN_ - 1) / BN_);       \
+            unsigned ntm_ = (unsigned)((g.M + BM_ - 1) / BM_);                                                      \
+            const unsigned ntn_ = (unsigned)((g.N + BN_ - 1) / BN_);                                               \
+            if (g.s2) { ntm_ = 0; for (int c_ = 0; c_ < 4; ++c_) ntm_ += (unsigned)((g.cls_n[c_] + BM_ - 1) / BM_); } \
             hipLaunchKernelGGL(kern_, dim3(8 * ntn_ * ((ntm_ + 7) / 8)), dim3(NT_), lds_, s, xp, wp, g, ep);        \
         } while (0)
         if (bm == 256 && bn == 256) SSD_LAUNCH_DMA(256, 256);
@@ -1401,7 +1482,7 @@ static void wgrad_patch_plan(int B, int Ho, int Wo, int Cin, int Cout, int* tile
     *tiles_x = (Wo + 15) / 16; *tiles_y = (Ho + 15) / 16;
     const int ntiles = B * *tiles_x * *tiles_y;
     const int groups = (Cin / 64) * ((Cout + 63) / 64);
-    int want = 512 / groups;                                 // ~2 rounds of one workgroup per CU
+    int want = 256 / groups;                                 // one workgroup per CU
     if (want < 1) want = 1;
     if (want > ntiles) want = ntiles;
     *tps = (ntiles + want - 1) / want;

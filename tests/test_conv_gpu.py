@@ -43,6 +43,8 @@ CASES = [
     (1, 50, 35, 128, 128, 3, 1, "same"),     # LDS-patch kernel, BN = 128, non-square, both dims partial
     (2, 33, 33, 192, 96, 3, 1, "same"),      # LDS-patch kernel, three chunks, N not a multiple of 32
     (1, 70, 70, 256, 320, 3, 1, "same"),     # 256-wide tiles of the LDS-DMA implicit GEMM (M = 4900, N = 320)
+    (2, 38, 38, 64, 128, 3, 2, "same"),      # stride-2 data gradient by parity classes (even size, pad (0,1))
+    (3, 19, 19, 128, 64, 3, 2, "same"),      # stride-2 data gradient by parity classes (odd size, pad (1,1))
 ]
 
 

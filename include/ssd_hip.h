@@ -159,20 +159,25 @@ int ssd_nms(const float* score, const int32_t* cls, const float* box, const uint
  * pad_total = max((Ho-1)*stride + k - H, 0), pad_t = pad_total/2 (the remainder goes after).
  * Channel counts of activation tensors must be multiples of 8 (the 3-channel image is expanded to 8
  * zero-padded channels by ssd_image_prep).
+ * (ws, ws_bytes) of the forward / data-gradient calls is OPTIONAL scratch (may be NULL/0): when given, skinny
+ * problems (few output tiles, long reduction) are split over k with a fixed-order fp32 reduction; a few MB suffice
+ * (ksplit * B*Ho*Wo * Cout * 4 bytes, only used when the layer has < 160 output tiles).
  * ---------------------------------------------------------------------------------------- */
 /* y[B,Ho,Wo,Cout] = relu?(conv(x[B,H,W,Cin], w) + bias)          Conv2D, :86-151 and the VGG blocks :77-82 */
 int ssd_conv2d_fwd(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin,
-                   int Cout, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int relu, void* stream);
+                   int Cout, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int relu, void* ws,
+                   size_t ws_bytes, void* stream);
 /* One pyramid level's loc+conf heads as ONE 3x3 SAME GEMM (N = per_cell*(4+classes); weight rows: loc filters
  * then conf filters), written straight into the concatenated outputs loc[B,A,4] / conf[B,A,classes]
  * (:155-167: the Reshape + Concatenate are the store addressing). */
 int ssd_conv2d_head_fwd(const void* x, const void* w, const float* bias, void* loc, void* conf, int B, int H, int W,
-                        int Cin, int per_cell, int classes, int anchors_total, int level_off, void* stream);
+                        int Cin, int per_cell, int classes, int anchors_total, int level_off, void* ws, size_t ws_bytes,
+                        void* stream);
 /* dx[B,H,W,Cin] (+)= conv_transpose(dy[B,Ho,Wo,Cout_pad], w_t), then zeroed where relu_src <= 0 (relu_src =
  * the forward activation stored in dx's place, or NULL).  w_t from ssd_weight_transpose. */
 int ssd_conv2d_bwd_data(const void* dy, const void* w_t, const void* relu_src, void* dx, int B, int H, int W, int Cin,
                         int Cout_pad, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int accumulate,
-                        void* stream);
+                        void* ws, size_t ws_bytes, void* stream);
 /* dw f32 [Cout][k][k][Cin], dbias f32 [Cout] (or NULL) from x[B,H,W,Cin] and dy[B,Ho,Wo,ldy] (first Cout
  * channels).  Deterministic (fixed-order split reduction). */
 size_t ssd_conv2d_bwd_weight_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ldy, int ksize);

@@ -35,9 +35,9 @@ _SIGNATURES = {
                                         ctypes.c_float, ctypes.c_double, VP, VP, VP, VP, VP]),
     "ssd_nms_max_candidates": (ctypes.c_int, []),
     "ssd_nms": (ctypes.c_int, [VP, VP, VP, VP, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, VP, VP, VP]),
-    "ssd_conv2d_fwd": (ctypes.c_int, [VP, VP, VP, VP] + [ctypes.c_int] * 12 + [VP]),
-    "ssd_conv2d_head_fwd": (ctypes.c_int, [VP, VP, VP, VP, VP] + [ctypes.c_int] * 8 + [VP]),
-    "ssd_conv2d_bwd_data": (ctypes.c_int, [VP, VP, VP, VP] + [ctypes.c_int] * 12 + [VP]),
+    "ssd_conv2d_fwd": (ctypes.c_int, [VP, VP, VP, VP] + [ctypes.c_int] * 12 + [VP, ctypes.c_size_t, VP]),
+    "ssd_conv2d_head_fwd": (ctypes.c_int, [VP, VP, VP, VP, VP] + [ctypes.c_int] * 8 + [VP, ctypes.c_size_t, VP]),
+    "ssd_conv2d_bwd_data": (ctypes.c_int, [VP, VP, VP, VP] + [ctypes.c_int] * 12 + [VP, ctypes.c_size_t, VP]),
     "ssd_conv2d_bwd_weight_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 7),
     "ssd_conv2d_bwd_weight": (ctypes.c_int, [VP, VP, VP, VP] + [ctypes.c_int] * 12 + [VP, ctypes.c_size_t, VP]),
     "ssd_weight_transpose": (ctypes.c_int, [VP, VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, VP]),

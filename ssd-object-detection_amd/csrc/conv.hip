@@ -96,6 +96,10 @@ struct Epilogue {
     int level_off;                           // first anchor of this level
     int per_cell;                            // n
     int classes;                             // C
+    // split-K: when slab != null the kernel stores raw fp32 partial sums to slab[split][M][N] and k_igemm_finalize
+    // applies the epilogue to their fixed-order sum
+    float* slab;
+    int ksplit;
 };
 
 __device__ __forceinline__ float bf2f(bf16_raw v) { return __uint_as_float((unsigned)v << 16); }
@@ -112,6 +116,76 @@ __device__ __forceinline__ int swz(int row, int chunk) {
 
 // Epilogue shared by the implicit-GEMM kernels: lane holds channels n_base + (lane>>4)*4 + {0..3} of pixel
 // m_base + (lane&15) for every (channel tile, pixel tile) of its wave.
+// Store 4 consecutive output channels n..n+3 of output pixel m (bias already added to v).
+template <int EPI>
+__device__ __forceinline__ void epi_store(float (&v)[4], int m, int n, bool full, const ConvGeom& g, const Epilogue& ep) {
+    if constexpr (EPI == EPI_FWD) {
+        if (ep.relu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        bf16_raw* o = ep.out + (long long)m * ep.ldo + n;
+        if (full) {
+            *reinterpret_cast<uint2*>(o) = make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16),
+                                                      (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (n + j < g.N) o[j] = f2bf(v[j]);
+        }
+    } else if constexpr (EPI == EPI_DGRAD) {
+        bf16_raw* o = ep.out + (long long)m * ep.ldo + n;
+        const bf16_raw* ms = ep.mask_src ? ep.mask_src + (long long)m * ep.ldo + n : nullptr;
+        if (full) {
+            if (ep.accumulate) {
+                const uint2 old = *reinterpret_cast<const uint2*>(o);
+                v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
+                v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
+            }
+            if (ms) {
+                const uint2 mk = *reinterpret_cast<const uint2*>(ms);
+                if (!(__uint_as_float(mk.x << 16) > 0.f)) v[0] = 0.f;
+                if (!(__uint_as_float(mk.x & 0xffff0000u) > 0.f)) v[1] = 0.f;
+                if (!(__uint_as_float(mk.y << 16) > 0.f)) v[2] = 0.f;
+                if (!(__uint_as_float(mk.y & 0xffff0000u) > 0.f)) v[3] = 0.f;
+            }
+            *reinterpret_cast<uint2*>(o) = make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16),
+                                                      (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (n + j >= g.N) continue;
+                float r = v[j];
+                if (ep.accumulate) r += bf2f(o[j]);
+                if (ms && !(bf2f(ms[j]) > 0.f)) r = 0.f;
+                o[j] = f2bf(r);
+            }
+        }
+    } else {  // EPI_HEAD: scatter into loc [B][A][4] and conf [B][A][classes]
+        const int b = fdiv(m, g.d_hw);
+        const int pix = m - b * g.d_hw.d;
+        const long long anchor0 = (long long)b * ep.anchors_total + ep.level_off + (long long)pix * ep.per_cell;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nn = n + j;
+            if (nn >= ep.n_loc + ep.n_conf) continue;
+            if (nn < ep.n_loc) ep.loc[anchor0 * 4 + nn] = f2bf(v[j]);
+            else ep.conf[anchor0 * ep.classes + (nn - ep.n_loc)] = f2bf(v[j]);
+        }
+    }
+}
+
+__device__ __forceinline__ void load_bias4(const Epilogue& ep, int n, int N, bool full, float (&b4)[4]) {
+    b4[0] = b4[1] = b4[2] = b4[3] = 0.f;
+    if (!ep.bias) return;
+    if (full) {
+        const float4 bv = *reinterpret_cast<const float4*>(ep.bias + n);
+        b4[0] = bv.x; b4[1] = bv.y; b4[2] = bv.z; b4[3] = bv.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (n + j < N) b4[j] = ep.bias[n + j];
+    }
+}
+
 template <int EPI, int CT, int PT>
 __device__ __forceinline__ void conv_epilogue_rows(f32x4_t (&acc)[CT][PT], const ConvGeom& g, const Epilogue& ep,
                                                    const int (&mrow)[PT], int nbase, int lane) {
@@ -121,78 +195,52 @@ __device__ __forceinline__ void conv_epilogue_rows(f32x4_t (&acc)[CT][PT], const
         const int n = nbase + c * 16 + (lane >> 4) * 4;
         if (n >= g.N) continue;
         const bool full = n + 3 < g.N;
-        float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (EPI == EPI_FWD || EPI == EPI_HEAD) {
-            if (ep.bias) {
-                if (full) {
-                    const float4 bv = *reinterpret_cast<const float4*>(ep.bias + n);
-                    bias4[0] = bv.x; bias4[1] = bv.y; bias4[2] = bv.z; bias4[3] = bv.w;
-                } else {
+        if (ep.slab) {                           // split-K partial sums (uniform branch)
+            float* sl = ep.slab + (long long)blockIdx.y * g.M * g.N;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (n + j < g.N) bias4[j] = ep.bias[n + j];
-                }
+            for (int p = 0; p < PT; ++p) {
+                const int m = mrow[p];
+                if (m < 0) continue;
+                float* o = sl + (long long)m * g.N + n;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (n + j < g.N) o[j] = acc[c][p][j];
             }
+            continue;
         }
+        float bias4[4];
+        if constexpr (EPI == EPI_DGRAD) { bias4[0] = bias4[1] = bias4[2] = bias4[3] = 0.f; }
+        else load_bias4(ep, n, g.N, full, bias4);
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
             const int m = mrow[p];
             if (m < 0) continue;
             float v[4] = {acc[c][p][0] + bias4[0], acc[c][p][1] + bias4[1], acc[c][p][2] + bias4[2], acc[c][p][3] + bias4[3]};
-            if constexpr (EPI == EPI_FWD) {
-                if (ep.relu) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-                }
-                bf16_raw* o = ep.out + (long long)m * ep.ldo + n;
-                if (full) {
-                    *reinterpret_cast<uint2*>(o) = make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16),
-                                                              (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) if (n + j < g.N) o[j] = f2bf(v[j]);
-                }
-            } else if constexpr (EPI == EPI_DGRAD) {
-                bf16_raw* o = ep.out + (long long)m * ep.ldo + n;
-                const bf16_raw* ms = ep.mask_src ? ep.mask_src + (long long)m * ep.ldo + n : nullptr;
-                if (full) {
-                    if (ep.accumulate) {
-                        const uint2 old = *reinterpret_cast<const uint2*>(o);
-                        v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
-                        v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
-                    }
-                    if (ms) {
-                        const uint2 mk = *reinterpret_cast<const uint2*>(ms);
-                        if (!(__uint_as_float(mk.x << 16) > 0.f)) v[0] = 0.f;
-                        if (!(__uint_as_float(mk.x & 0xffff0000u) > 0.f)) v[1] = 0.f;
-                        if (!(__uint_as_float(mk.y << 16) > 0.f)) v[2] = 0.f;
-                        if (!(__uint_as_float(mk.y & 0xffff0000u) > 0.f)) v[3] = 0.f;
-                    }
-                    *reinterpret_cast<uint2*>(o) = make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16),
-                                                              (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (n + j >= g.N) continue;
-                        float r = v[j];
-                        if (ep.accumulate) r += bf2f(o[j]);
-                        if (ms && !(bf2f(ms[j]) > 0.f)) r = 0.f;
-                        o[j] = f2bf(r);
-                    }
-                }
-            } else {  // EPI_HEAD: scatter into loc [B][A][4] and conf [B][A][classes]
-                const int b = fdiv(m, g.d_hw);
-                const int pix = m - b * g.d_hw.d;
-                const long long anchor0 = (long long)b * ep.anchors_total + ep.level_off + (long long)pix * ep.per_cell;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int nn = n + j;
-                    if (nn >= ep.n_loc + ep.n_conf) continue;
-                    if (nn < ep.n_loc) ep.loc[anchor0 * 4 + nn] = f2bf(v[j]);
-                    else ep.conf[anchor0 * ep.classes + (nn - ep.n_loc)] = f2bf(v[j]);
-                }
-            }
+            epi_store<EPI>(v, m, n, full, g, ep);
         }
     }
+}
+
+// split-K finalize: out = epilogue(sum over splits of slab[split][m][n..n+3] + bias)
+template <int EPI>
+__global__ void k_igemm_finalize(ConvGeom g, Epilogue ep) {
+    const int n4 = (g.N + 3) >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)g.M * n4) return;
+    const int m = (int)(idx / n4), n = (int)(idx - (long long)m * n4) * 4;
+    const bool full = n + 3 < g.N;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < ep.ksplit; ++z) {
+        const float* sl = ep.slab + ((long long)z * g.M + m) * g.N + n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (n + j < g.N) v[j] += sl[j];
+    }
+    if constexpr (EPI != EPI_DGRAD) {
+        float b4[4];
+        load_bias4(ep, n, g.N, false, b4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += b4[j];
+    }
+    epi_store<EPI>(v, m, n, full, g, ep);
 }
 
 template <int BN, int EPI, int CT, int PT>
@@ -476,16 +524,28 @@ __global__ __launch_bounds__((BM / (16 * PT)) * (BN >= 128 ? BN / 64 : 2) * 64) 
         cc = sub * 8 + slot;
         q = t * g.cpt + cc;
     };
-    if (g.s2 && nks > 0) set_step(0);
-    if (nks > 0) issue_dma(0);
+    // split-K: this workgroup covers k-steps [ks0, ks1)
+    int ks0 = 0, ks1 = nks;
+    if (ep.slab) {
+        const int per = (nks + ep.ksplit - 1) / ep.ksplit;
+        ks0 = min(nks, (int)blockIdx.y * per);
+        ks1 = min(nks, ks0 + per);
+        if (!g.s2) {                              // position the incremental k state on step ks0
+            q = ks0 * 8 + slot;
+            tap = q / g.cpt; cc = q - tap * g.cpt;
+            kh = tap / g.KW; kw = tap - kh * g.KW;
+        }
+    }
+    if (g.s2 && ks0 < ks1) set_step(ks0);
+    if (ks0 < ks1) issue_dma(0);
     const int frow = lane & 15, fk = lane >> 4;
-    for (int ks = 0; ks < nks; ++ks) {
-        const int cur = ks & 1;
+    for (int ks = ks0; ks < ks1; ++ks) {
+        const int cur = (ks - ks0) & 1;
         if (!(g.ablate & 2)) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
-        if (ks + 1 < nks && !(g.ablate & 1)) {
+        if (ks + 1 < ks1 && !(g.ablate & 1)) {
             if (g.s2) set_step(ks + 1);
             issue_dma(cur ^ 1);
         }
@@ -1337,9 +1397,13 @@ int igemm_variant() {                       // SSD_CONV_VARIANT=0: register-stag
 }
 
 template <int EPI>
-int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue& ep, hipStream_t s) {
+int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue& ep_in, hipStream_t s, void* ws = nullptr,
+                 size_t ws_bytes = 0) {
     const bf16_raw* xp = static_cast<const bf16_raw*>(x);
     const bf16_raw* wp = static_cast<const bf16_raw*>(w);
+    Epilogue ep = ep_in;
+    ep.slab = nullptr;
+    ep.ksplit = 1;
     const unsigned gm = (unsigned)((g.M + 127) / 128);
     static int use_patch = -1;
     if (use_patch < 0) { const char* e = getenv("SSD_CONV_PATCH"); use_patch = e ? atoi(e) : 128; }   // max N served
@@ -1376,6 +1440,21 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
         else if (g.N <= 64 && wg_256 >= 384) { bm = 256; bn = 64; }
         if (force == 1) { bm = 128; bn = g.N <= 64 ? 64 : 128; }
         (void)wg_128;
+        // split-K for skinny problems (few tiles, long k loop): partial sums to the caller's workspace
+        unsigned ksplit = 1;
+        {
+            static int sk_on = -1;
+            if (sk_on < 0) { const char* e = getenv("SSD_SPLITK"); sk_on = e ? atoi(e) : 1; }
+            const long long tiles = (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn);
+            const int nks_all = g.s2 ? 0 : (g.nchunks + 7) / 8;
+            if (sk_on && ws && tiles < 160 && nks_all >= 8) {
+                long long want = (256 + tiles - 1) / tiles;
+                if (want > nks_all / 2) want = nks_all / 2;
+                if (want > 32) want = 32;
+                while (want > 1 && (size_t)want * g.M * g.N * sizeof(float) > ws_bytes) --want;
+                if (want > 1) { ksplit = (unsigned)want; ep.slab = static_cast<float*>(ws); ep.ksplit = (int)want; }
+            }
+        }
 #define SSD_LAUNCH_DMA(BM_, BN_)                                                                                   \
         do {                                                                                                       \
             constexpr int PT_ = (BM_ == 256 && BN_ == 256) ? SSD_PT256 : 4;                                         \
@@ -1394,7 +1473,7 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
             unsigned ntm_ = (unsigned)((g.M + BM_ - 1) / BM_);                                                      \
             const unsigned ntn_ = (unsigned)((g.N + BN_ - 1) / BN_);                                               \
             if (g.s2) { ntm_ = 0; for (int c_ = 0; c_ < 4; ++c_) ntm_ += (unsigned)((g.cls_n[c_] + BM_ - 1) / BM_); } \
-            hipLaunchKernelGGL(kern_, dim3(8 * ntn_ * ((ntm_ + 7) / 8)), dim3(NT_), lds_, s, xp, wp, g, ep);        \
+            hipLaunchKernelGGL(kern_, dim3(8 * ntn_ * ((ntm_ + 7) / 8), ksplit), dim3(NT_), lds_, s, xp, wp, g, ep); \
         } while (0)
         if (bm == 256 && bn == 256) SSD_LAUNCH_DMA(256, 256);
         else if (bm == 256 && bn == 128) SSD_LAUNCH_DMA(256, 128);
@@ -1402,6 +1481,11 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
         else if (bn == 64) SSD_LAUNCH_DMA(128, 64);
         else SSD_LAUNCH_DMA(128, 128);
 #undef SSD_LAUNCH_DMA
+        if (ksplit > 1) {
+            if (hipGetLastError() != hipSuccess) return SSD_ERR_LAUNCH;
+            const long long nthr = (long long)g.M * ((g.N + 3) / 4);
+            hipLaunchKernelGGL(k_igemm_finalize<EPI>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, g, ep);
+        }
         return ssd_launch_status();
     }
     if (g.N <= 64) {
@@ -1427,16 +1511,18 @@ bool geom_ok(int B, int H, int W, int C, int Ho, int Wo, int N, int K) {
 extern "C" {
 
 int ssd_conv2d_fwd(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
-                   int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int relu, void* stream) {
+                   int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int relu, void* ws, size_t ws_bytes,
+                   void* stream) {
     if (!x || !w || !y || !geom_ok(B, H, W, Cin, Ho, Wo, Cout, ksize) || stride <= 0) return SSD_ERR_VALUE;
     const ConvGeom g = make_geom(B, H, W, Cin, Ho, Wo, Cout, ksize, ksize, stride, 1, pad_t, pad_l);
     Epilogue ep = {};
     ep.bias = bias; ep.relu = relu; ep.out = static_cast<bf16_raw*>(y); ep.ldo = Cout;
-    return launch_igemm<EPI_FWD>(x, w, g, ep, (hipStream_t)stream);
+    return launch_igemm<EPI_FWD>(x, w, g, ep, (hipStream_t)stream, ws, ws_bytes);
 }
 
 int ssd_conv2d_head_fwd(const void* x, const void* w, const float* bias, void* loc, void* conf, int B, int H, int W,
-                        int Cin, int per_cell, int classes, int anchors_total, int level_off, void* stream) {
+                        int Cin, int per_cell, int classes, int anchors_total, int level_off, void* ws, size_t ws_bytes,
+                        void* stream) {
     const int N = per_cell * (4 + classes);
     if (!x || !w || !loc || !conf || !geom_ok(B, H, W, Cin, H, W, N, 3) || per_cell <= 0 || classes <= 0) return SSD_ERR_VALUE;
     const ConvGeom g = make_geom(B, H, W, Cin, H, W, N, 3, 3, 1, 1, 1, 1);   // 3x3 SAME stride 1 (models/ssd_model.py:155-162)
@@ -1444,12 +1530,12 @@ int ssd_conv2d_head_fwd(const void* x, const void* w, const float* bias, void* l
     ep.bias = bias; ep.loc = static_cast<bf16_raw*>(loc); ep.conf = static_cast<bf16_raw*>(conf);
     ep.n_loc = per_cell * 4; ep.n_conf = per_cell * classes; ep.anchors_total = anchors_total;
     ep.level_off = level_off; ep.per_cell = per_cell; ep.classes = classes;
-    return launch_igemm<EPI_HEAD>(x, w, g, ep, (hipStream_t)stream);
+    return launch_igemm<EPI_HEAD>(x, w, g, ep, (hipStream_t)stream, ws, ws_bytes);
 }
 
 int ssd_conv2d_bwd_data(const void* dy, const void* w_t, const void* relu_src, void* dx, int B, int H, int W, int Cin,
                         int Cout_pad, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int accumulate,
-                        void* stream) {
+                        void* ws, size_t ws_bytes, void* stream) {
     // dy: [B,Ho,Wo,Cout_pad]; w_t: [Cin][k][k][Cout_pad] (ssd_weight_transpose); dx, relu_src: [B,H,W,Cin]
     if (!dy || !w_t || !dx || !geom_ok(B, Ho, Wo, Cout_pad, H, W, Cin, ksize) || stride <= 0) return SSD_ERR_VALUE;
     const ConvGeom g = make_geom(B, Ho, Wo, Cout_pad, H, W, Cin, ksize, ksize, 1, stride, ksize - 1 - pad_t,
@@ -1457,7 +1543,7 @@ int ssd_conv2d_bwd_data(const void* dy, const void* w_t, const void* relu_src, v
     Epilogue ep = {};
     ep.out = static_cast<bf16_raw*>(dx); ep.ldo = Cin; ep.mask_src = static_cast<const bf16_raw*>(relu_src);
     ep.accumulate = accumulate;
-    return launch_igemm<EPI_DGRAD>(dy, w_t, g, ep, (hipStream_t)stream);
+    return launch_igemm<EPI_DGRAD>(dy, w_t, g, ep, (hipStream_t)stream, ws, ws_bytes);
 }
 
 static int wgrad_dma() {                    // SSD_WGRAD_DMA=1: LDS-DMA weight-gradient kernel (default: register-staged)

@@ -215,7 +215,7 @@ class SSDEngine:
             if nd["kind"] == "conv":
                 wt, bt = self.conv_params[i]
                 ops.conv2d_fwd(acts[i], self.view(wt, self.param_bf16), self.view(bt, self.param), nd["stride"],
-                               nd["pt"], nd["pl"], nd["hout"], nd["hout"], True, out=acts[i + 1])
+                               nd["pt"], nd["pl"], nd["hout"], nd["hout"], True, out=acts[i + 1], ws=self._ws)
             else:
                 L = self.L
                 _lib.check(L.ssd_maxpool2x2_fwd(ops._ptr(acts[i]), ops._ptr(acts[i + 1]), B, nd["hin"], nd["hin"],
@@ -223,7 +223,7 @@ class SSDEngine:
         for lvl, (ni, h, ch) in enumerate(self.fm):
             wt, bt = self.head_params[lvl]
             ops.conv2d_head_fwd(acts[ni + 1], self.view(wt, self.param_bf16), self.view(bt, self.param), c["loc"],
-                                c["conf"], self.num_priors[lvl], self.classes, self.level_off[lvl])
+                                c["conf"], self.num_priors[lvl], self.classes, self.level_off[lvl], ws=self._ws)
         return c["loc"], c["conf"]
 
     def backward(self, dloc, dconf, on_ready=None):
@@ -244,7 +244,7 @@ class SSDEngine:
             if on_ready:
                 on_ready([wt.index, bt.index])
             ops.conv2d_bwd_data(packed, self.head_w_t[lvl], acts[ni + 1], acts[ni + 1].shape, 1, 1, 1,
-                                accumulate=False, out=gacts[ni + 1])
+                                accumulate=False, out=gacts[ni + 1], ws=self._ws)
             written[ni + 1] = True
         # trunk, last layer first
         for i in range(len(self.nodes) - 1, -1, -1):
@@ -264,7 +264,7 @@ class SSDEngine:
                 continue                          # no gradient w.r.t. the image
             prev_is_relu_conv = self.nodes[i - 1]["kind"] == "conv"
             ops.conv2d_bwd_data(g_out, self.w_t[i], acts[i] if prev_is_relu_conv else None, acts[i].shape, nd["stride"],
-                                nd["pt"], nd["pl"], accumulate=written[i], out=gacts[i])
+                                nd["pt"], nd["pl"], accumulate=written[i], out=gacts[i], ws=self._ws)
             written[i] = True
 
     # ---------------------------------------------------------------- optimizer

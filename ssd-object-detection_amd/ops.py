@@ -246,7 +246,12 @@ def image_prep(img, normalize=True):
     return out
 
 
-def conv2d_fwd(x, w, bias, stride, pad_t, pad_l, Ho, Wo, relu, out=None):
+def _splitk_ws(ws):
+    buf = (ws or _conv_ws).get(1 << 25, torch.device("cuda", torch.cuda.current_device()))   # >= 32 MiB of scratch
+    return buf
+
+
+def conv2d_fwd(x, w, bias, stride, pad_t, pad_l, Ho, Wo, relu, out=None, ws=None):
     L = _lib.lib()
     _bf(x); _bf(w)
     B, H, W, Cin = x.shape
@@ -254,19 +259,21 @@ def conv2d_fwd(x, w, bias, stride, pad_t, pad_l, Ho, Wo, relu, out=None):
     assert w.shape == (Cout, k, k, Cin)
     if out is None:
         out = torch.empty((B, Ho, Wo, Cout), dtype=torch.bfloat16, device=x.device)
+    wbuf = _splitk_ws(ws)
     _lib.check(L.ssd_conv2d_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), B, H, W, Cin, Cout, k, stride, pad_t, pad_l,
-                                Ho, Wo, 1 if relu else 0, _stream()))
+                                Ho, Wo, 1 if relu else 0, _ptr(wbuf), wbuf.numel(), _stream()))
     return out
 
 
-def conv2d_head_fwd(x, w, bias, loc, conf, per_cell, classes, level_off):
+def conv2d_head_fwd(x, w, bias, loc, conf, per_cell, classes, level_off, ws=None):
     L = _lib.lib()
     _bf(x); _bf(w); _bf(loc); _bf(conf)
     B, H, W, Cin = x.shape
     A = loc.shape[1]
     assert w.shape == (per_cell * (4 + classes), 3, 3, Cin)
+    wbuf = _splitk_ws(ws)
     _lib.check(L.ssd_conv2d_head_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(loc), _ptr(conf), B, H, W, Cin, per_cell,
-                                     classes, A, level_off, _stream()))
+                                     classes, A, level_off, _ptr(wbuf), wbuf.numel(), _stream()))
 
 
 def weight_transpose(w, cout_pad=None, out=None):
@@ -280,7 +287,7 @@ def weight_transpose(w, cout_pad=None, out=None):
     return out
 
 
-def conv2d_bwd_data(dy, w_t, relu_src, x_shape, stride, pad_t, pad_l, accumulate=False, out=None):
+def conv2d_bwd_data(dy, w_t, relu_src, x_shape, stride, pad_t, pad_l, accumulate=False, out=None, ws=None):
     L = _lib.lib()
     _bf(dy); _bf(w_t)
     B, H, W, Cin = x_shape
@@ -290,8 +297,9 @@ def conv2d_bwd_data(dy, w_t, relu_src, x_shape, stride, pad_t, pad_l, accumulate
     if out is None:
         assert not accumulate
         out = torch.empty(x_shape, dtype=torch.bfloat16, device=dy.device)
+    wbuf = _splitk_ws(ws)
     _lib.check(L.ssd_conv2d_bwd_data(_ptr(dy), _ptr(w_t), _ptr(relu_src), _ptr(out), B, H, W, Cin, cpad, k, stride,
-                                     pad_t, pad_l, Ho, Wo, 1 if accumulate else 0, _stream()))
+                                     pad_t, pad_l, Ho, Wo, 1 if accumulate else 0, _ptr(wbuf), wbuf.numel(), _stream()))
     return out
 
 

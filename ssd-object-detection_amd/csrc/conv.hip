@@ -1088,7 +1088,7 @@ __device__ __forceinline__ int wp_key(int px) { return (px & 3) ^ (((px >> 3) & 
 __global__ __launch_bounds__(576) void k_conv3x3_wgrad_patch(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ dy,
                                                              float* __restrict__ slab_w, float* __restrict__ slab_b,
                                                              ConvGeom g, int tiles_x, int tiles_y, int tiles_per_split,
-                                                             int nsplit, int cout) {
+                                                             int nsplit, int cout, int single_buf) {
     // g: source = x (B,H,W,C), destination = dy (Ho=H, Wo=W, N = ldy)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     auto s_dy = [&](int buf) { return smem + buf * WP_BUF; };
@@ -1156,13 +1156,15 @@ __global__ __launch_bounds__(576) void k_conv3x3_wgrad_patch(const bf16_raw* __r
 #pragma unroll
     for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
 
+    // single_buf: one LDS buffer (74 KB) so that TWO workgroups share a CU and hide each other's DMA latency;
+    // otherwise two buffers in one workgroup (150 KB), next block's DMA in flight during this block's MFMAs
     if (t_begin < t_end) issue_dma(t_begin, 0);
     const int gq = lane >> 4, li = lane & 15;
     for (int t = t_begin; t < t_end; ++t) {
-        const int cur = (t - t_begin) & 1;
+        const int cur = single_buf ? 0 : (t - t_begin) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (t + 1 < t_end) issue_dma(t + 1, cur ^ 1);
+        if (!single_buf && t + 1 < t_end) issue_dma(t + 1, cur ^ 1);
         const char* pdy = s_dy(cur);
         const char* ppx = s_px(cur);
 #pragma unroll 2
@@ -1196,6 +1198,10 @@ __global__ __launch_bounds__(576) void k_conv3x3_wgrad_patch(const bf16_raw* __r
 #pragma unroll
                 for (int a = 0; a < 4; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], ones, accb[a], 0, 0, 0);
             }
+        }
+        if (single_buf && t + 1 < t_end) {
+            __syncthreads();                                 // everybody is done reading the buffer
+            issue_dma(t + 1, 0);
         }
     }
     // slab[split][co][tap][ci]  (dW layout [Cout][kh][kw][Cin], rows = ldy channels)
@@ -1568,7 +1574,9 @@ static void wgrad_patch_plan(int B, int Ho, int Wo, int Cin, int Cout, int* tile
     *tiles_x = (Wo + 15) / 16; *tiles_y = (Ho + 15) / 16;
     const int ntiles = B * *tiles_x * *tiles_y;
     const int groups = (Cin / 64) * ((Cout + 63) / 64);
-    int want = 256 / groups;                                 // one workgroup per CU
+    static int wp_mult = -1;
+    if (wp_mult < 0) { const char* e = getenv("SSD_WGRAD_PATCH_SINGLE"); wp_mult = (e && atoi(e)) ? 2 : 1; }
+    int want = 256 * wp_mult / groups;                       // one (two when single-buffered) workgroup per CU
     if (want < 1) want = 1;
     if (want > ntiles) want = ntiles;
     *tps = (ntiles + want - 1) / want;
@@ -1621,16 +1629,18 @@ int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias
         float* slab_w = static_cast<float*>(ws);
         float* slab_b = slab_w + (size_t)ns * ldy * ktot;
         hipStream_t s = (hipStream_t)stream;
-        const size_t lds = 2 * WP_BUF;
+        static int single = -1;
+        if (single < 0) { const char* e = getenv("SSD_WGRAD_PATCH_SINGLE"); single = e ? atoi(e) : 0; }
+        const size_t lds = (single ? 1 : 2) * WP_BUF;
         static bool set = false;
         if (!set) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_wgrad_patch), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds) != hipSuccess) return SSD_ERR_LAUNCH;
+                                    2 * WP_BUF) != hipSuccess) return SSD_ERR_LAUNCH;
             set = true;
         }
         const unsigned grid = (unsigned)((Cin / 64) * ((Cout + 63) / 64) * ns);
         hipLaunchKernelGGL(k_conv3x3_wgrad_patch, dim3(grid), dim3(576), lds, s, static_cast<const bf16_raw*>(x),
-                           static_cast<const bf16_raw*>(dy), slab_w, dbias ? slab_b : nullptr, g, tx, ty, tps, ns, Cout);
+                           static_cast<const bf16_raw*>(dy), slab_w, dbias ? slab_b : nullptr, g, tx, ty, tps, ns, Cout, single);
         if (hipGetLastError() != hipSuccess) return SSD_ERR_LAUNCH;
         const long long nw = (long long)Cout * ktot;
         hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, slab_w, (long long)ldy * ktot,

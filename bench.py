@@ -156,11 +156,18 @@ def main():
                 ops.match_encode(*gt, pset, 0.5, out=match_out)
         t_match = timed(lambda: g.replay(), 50)
         mbytes = B * MATCH_BYTES_PER_IMAGE + 20 * total_gt
+        # HBM traffic of the dominant matching kernel from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE
+        # runs of tools_dev/time_match.py 64:mix; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "r01_match_pmc.json")
+        if B == 64 and os.path.exists(pmc_file):
+            pmc = json.load(open(pmc_file))
+            traffic = int((2 * pmc["k_match_pairs.FETCH_SIZE"] + pmc["k_match_pairs.WRITE_SIZE"]) * 1024)
         result["roofline_match"] = {
             "bound": "hbm", "kernel": "ssd_match_encode (k_match_rows + k_match_pairs + k_match_phase1)",
             "achieved": round(mbytes / t_match / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": round(mbytes / t_match / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
-            "us_per_image": round(t_match / B * 1e6, 4), "total_gt": total_gt}
+            "frac": round(mbytes / t_match / 1e9 / PEAK_HBM_GBS, 4), "traffic": traffic,
+            "algorithmic_bytes": mbytes, "us_per_image": round(t_match / B * 1e6, 4), "total_gt": total_gt}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(np, torch)

@@ -607,8 +607,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_patch(const bf16_raw* __restric
     constexpr int WI = BN / 64;                              // weight DMA instructions per wave per tap
     constexpr int PI = (PATCH_INSTR + 7) / 8;                // patch DMA instructions per wave per chunk (<= 6)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    auto s_w = [&](int buf) { return smem + buf * (BN * 128); };           // 3 weight buffers (two taps ahead)
-    auto s_p = [&](int buf) { return smem + 3 * (BN * 128) + buf * PATCH_BYTES; };
+    // LDS: two weight buffers + ONE patch buffer = 58 / 75 KB, so that two workgroups share a CU and cover each other's
+    // barrier and DMA waits (a second patch buffer or a third weight buffer would drop that to one and was slower)
+    auto s_w = [&](int buf) { return smem + buf * (BN * 128); };
+    auto s_p = [&](int) { return smem + 2 * (BN * 128); };
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -672,35 +674,20 @@ __global__ __launch_bounds__(512) void k_conv3x3_patch(const bf16_raw* __restric
 #pragma unroll
         for (int p = 0; p < PT; ++p) acc[c][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    // Counted waits: DMAs complete in issue order, so "all but the N newest" = everything issued before the
-    // previous step's batch.  A step's batch = WI weight instructions (+ this wave's patch instructions when the
-    // next chunk's patch is prefetched, at tap 0).
-    const int my_patch = wave == 0 ? (PATCH_INSTR + 7) / 8 : (PATCH_INSTR - wave + 7) / 8;
-    auto wait_all_but = [&](int n) {
-        switch (n) {
-            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        }
-    };
     dma_patch(0, 0);
     dma_w(0, 0);
-    if (nsteps > 1) dma_w(1, 1);
-    int last_batch = nsteps > 1 ? WI : 0;          // instructions issued after the data step 0 needs
     const int frow = lane & 15, fk = lane >> 4;
     int chunk = 0, tap = 0, kh = 0, kw = 0;
     for (int s = 0; s < nsteps; ++s) {
-        wait_all_but(last_batch);
-        asm volatile("s_barrier" ::: "memory");
-        last_batch = 0;
-        if (s + 2 < nsteps) { dma_w(s + 2, (s + 2) % 3); last_batch += WI; }
-        if (tap == 0 && chunk + 1 < nchunk) { dma_patch(chunk + 1, (chunk + 1) & 1); last_batch += my_patch; }
+        if (tap == 0 && s > 0) {
+            __syncthreads();                              // every wave is done with the previous chunk's patch
+            dma_patch(chunk, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s + 1 < nsteps) dma_w(s + 1, (s + 1) & 1);
         const char* pb = s_p(chunk & 1);
-        const char* wb = s_w(s % 3);
+        const char* wb = s_w(s & 1);
 #pragma unroll
         for (int ksub = 0; ksub < 2; ++ksub) {
             bf16x8_t fx[PT], fw[CT];
@@ -1239,6 +1226,29 @@ __global__ void k_wgrad_reduce(const float* __restrict__ slab, long long n, int 
     out[i] = s;
 }
 
+// weights and bias in one launch: blocks [0, nbw) reduce the first nw elements of the weight slab (stride sw per split)
+// four at a time, the remaining blocks the nb bias elements (stride sb)
+__global__ __launch_bounds__(256) void k_wgrad_reduce2(const float* __restrict__ slab_w, long long sw, long long nw,
+                                                       float* __restrict__ dw, const float* __restrict__ slab_b, long long sb,
+                                                       int nb, float* __restrict__ db, int nsplit, unsigned nbw) {
+    if (blockIdx.x < nbw) {
+        const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+        if (i >= nw) return;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int z = 0; z < nsplit; ++z) {
+            const float4 v = *reinterpret_cast<const float4*>(slab_w + (long long)z * sw + i);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4*>(dw + i) = s;
+    } else {
+        const int i = (int)(blockIdx.x - nbw) * 256 + threadIdx.x;
+        if (i >= nb) return;
+        float s = 0.f;
+        for (int z = 0; z < nsplit; ++z) s += slab_b[(long long)z * sb + i];
+        db[i] = s;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // W[co][kh][kw][ci] (bf16) -> Wt[ci][KH-1-kh][KW-1-kw][co] for the data gradient
 __global__ void k_weight_transpose(const bf16_raw* __restrict__ w, bf16_raw* __restrict__ wt, int Cout, int KH, int KW,
@@ -1416,19 +1426,18 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
     if (igemm_variant() >= 1 && g.KH == 3 && g.KW == 3 && g.mul == 1 && g.div == 1 && g.pad_t == 1 && g.pad_l == 1 &&
         g.C % 64 == 0 && g.H == g.Ho && g.W == g.Wo && g.N <= use_patch && g.H >= 16 && g.W >= 16) {
         const int tiles_x = (g.Wo + 15) / 16, tiles_y = (g.Ho + 15) / 16;
-        const int nchunk = g.C / 64;
         const unsigned gx = (unsigned)(tiles_x * tiles_y * g.B);
         if (g.N <= 64) {
-            const size_t lds = 3 * 64 * 128 + (nchunk > 1 ? 2 : 1) * PATCH_BYTES;
+            const size_t lds = 2 * 64 * 128 + PATCH_BYTES;
             auto kern = k_conv3x3_patch<64, EPI>;
             static bool set = false;
-            if (!set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 64 * 128 + 2 * PATCH_BYTES) != hipSuccess) return SSD_ERR_LAUNCH; set = true; }
+            if (!set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 128 + PATCH_BYTES) != hipSuccess) return SSD_ERR_LAUNCH; set = true; }
             hipLaunchKernelGGL(kern, dim3(gx, (unsigned)((g.N + 63) / 64)), dim3(512), lds, s, xp, wp, g, ep, tiles_x, tiles_y);
         } else {
-            const size_t lds = 3 * 128 * 128 + (nchunk > 1 ? 2 : 1) * PATCH_BYTES;
+            const size_t lds = 2 * 128 * 128 + PATCH_BYTES;
             auto kern = k_conv3x3_patch<128, EPI>;
             static bool set = false;
-            if (!set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 128 * 128 + 2 * PATCH_BYTES) != hipSuccess) return SSD_ERR_LAUNCH; set = true; }
+            if (!set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 128 + PATCH_BYTES) != hipSuccess) return SSD_ERR_LAUNCH; set = true; }
             hipLaunchKernelGGL(kern, dim3(gx, (unsigned)((g.N + 127) / 128)), dim3(512), lds, s, xp, wp, g, ep, tiles_x, tiles_y);
         }
         return ssd_launch_status();
@@ -1590,7 +1599,7 @@ static void wgrad_tiles(int Cout, long long ktot, int* bmo, int* bnc) {
 }
 
 static int wgrad_splits(long long M, int tiles) {
-    long long want = 1024 / tiles;                           // whole rounds: <= 4 workgroups per CU in total
+    long long want = 768 / tiles;                            // whole rounds: <= 3 workgroups per CU in total
     long long maxs = (M + 511) / 512;                        // at least 512 pixels per split
     if (want > maxs) want = maxs;
     if (want < 1) want = 1;
@@ -1642,11 +1651,10 @@ int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias
         hipLaunchKernelGGL(k_conv3x3_wgrad_patch, dim3(grid), dim3(576), lds, s, static_cast<const bf16_raw*>(x),
                            static_cast<const bf16_raw*>(dy), slab_w, dbias ? slab_b : nullptr, g, tx, ty, tps, ns, Cout, single);
         if (hipGetLastError() != hipSuccess) return SSD_ERR_LAUNCH;
-        const long long nw = (long long)Cout * ktot;
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, slab_w, (long long)ldy * ktot,
-                           ns, dw);
-        if (dbias) hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((Cout + 255) / 256)), dim3(256), 0, s, slab_b,
-                                      (long long)ldy, ns, dbias);
+        const long long nw = (long long)Cout * ktot;            // multiple of 4 (ktot = 9*Cin, Cin % 8 == 0)
+        const unsigned nbw = (unsigned)((nw / 4 + 255) / 256), nbb = dbias ? (unsigned)((Cout + 255) / 256) : 0u;
+        hipLaunchKernelGGL(k_wgrad_reduce2, dim3(nbw + nbb), dim3(256), 0, s, slab_w, (long long)ldy * ktot, nw, dw, slab_b,
+                           (long long)ldy, Cout, dbias, ns, nbw);
         return ssd_launch_status();
     }
     int bmo, bnc;
@@ -1698,11 +1706,10 @@ int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias
 #undef SSD_LAUNCH_WG
     }
     if (hipGetLastError() != hipSuccess) return SSD_ERR_LAUNCH;
-    const long long nw = (long long)Cout * ktot;             // rows >= Cout of the slab are padding channels
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, slab_w, (long long)ldy * ktot,
-                       ns, dw);
-    if (dbias) hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((Cout + 255) / 256)), dim3(256), 0, s, slab_b,
-                                  (long long)ldy, ns, dbias);
+    const long long nw = (long long)Cout * ktot;             // rows >= Cout of the slab are padding channels; nw % 4 == 0
+    const unsigned nbw = (unsigned)((nw / 4 + 255) / 256), nbb = dbias ? (unsigned)((Cout + 255) / 256) : 0u;
+    hipLaunchKernelGGL(k_wgrad_reduce2, dim3(nbw + nbb), dim3(256), 0, s, slab_w, (long long)ldy * ktot, nw, dw, slab_b,
+                       (long long)ldy, Cout, dbias, ns, nbw);
     return ssd_launch_status();
 }
 

@@ -77,6 +77,9 @@ struct ConvGeom {
 };
 
 enum { EPI_FWD = 0, EPI_HEAD = 1, EPI_DGRAD = 2 };
+#ifndef SSD_DMA_SLOT
+#define SSD_DMA_SLOT 0                        // 0: issue the next tile's DMA before the MFMAs, 1: between the two MFMA blocks
+#endif
 #ifndef SSD_PT256
 #define SSD_PT256 4                           // pixel tiles per wave of the 256x256 implicit-GEMM tile (8 = 8 waves of 128x64: no faster)
 #endif
@@ -545,12 +548,14 @@ __global__ __launch_bounds__((BM / (16 * PT)) * (BN >= 128 ? BN / 64 : 2) * 64) 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
-        if (ks + 1 < ks1 && !(g.ablate & 1)) {
-            if (g.s2) set_step(ks + 1);
-            issue_dma(cur ^ 1);
-        }
 #pragma unroll
         for (int ksub = 0; ksub < 2; ++ksub) {
+            // the next tile's DMA is issued between the two MFMA blocks: its address arithmetic and issue slots then
+            // overlap with MFMAs already in flight instead of sitting in front of them
+            if (ksub == SSD_DMA_SLOT && ks + 1 < ks1 && !(g.ablate & 1)) {
+                if (g.s2) set_step(ks + 1);
+                issue_dma(cur ^ 1);
+            }
             bf16x8_t fx[PT], fw[CT];
 #pragma unroll
             for (int p = 0; p < PT; ++p)
@@ -1450,7 +1455,8 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
         const long long wg_128 = (long long)((g.M + 127) / 128);
         const long long wg_256 = (long long)((g.M + 255) / 256);
         int bm = 128, bn = g.N <= 64 ? 64 : 128;
-        if (g.N > 128 && wg_256 * ((g.N + 255) / 256) >= 384) { bm = 256; bn = 256; }
+        const long long pad256 = (long long)((g.N + 255) / 256) * 256, pad128 = (long long)((g.N + 127) / 128) * 128;
+        if (g.N > 128 && wg_256 * ((g.N + 255) / 256) >= 384 && pad256 * 4 <= pad128 * 5) { bm = 256; bn = 256; }
         else if (g.N > 64 && wg_256 * ((g.N + 127) / 128) >= 384) { bm = 256; bn = 128; }
         else if (g.N <= 64 && wg_256 >= 384) { bm = 256; bn = 64; }
         if (force == 1) { bm = 128; bn = g.N <= 64 ? 64 : 128; }

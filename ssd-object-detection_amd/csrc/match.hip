@@ -26,7 +26,6 @@ namespace {
 
 constexpr int WG = 256;
 constexpr int NWAVE = WG / SSD_WAVE;
-constexpr int RT = 128;                      // gt rows staged in LDS per tile
 #define SSD_MARGIN (1.0 - 0x1p-50)           // filter slack: see DESIGN.md "division-free pruning"
 
 struct Corner {                              // (x_lo, y_lo, x_hi, y_hi, area) of one box, as f64
@@ -111,9 +110,12 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
 // K0: per gt row (32 lanes each): corner record + an exact seed of the row maximum taken from the
 // priors of the cell under the gt centre on every level (geometry hint).  The seed L is the IoU
 // of a real column of this row, hence L <= row maximum; lbm = L*(1-2^-50) is the pruning bound.
+constexpr int LIST_CAP = 48;                 // row candidates kept per gt row
+struct __attribute__((aligned(16))) Cand { double q; int c; int pad; };
+
 __global__ __launch_bounds__(WG) void k_match_rows(const float4* __restrict__ gt_box, int total_gt,
                                                    const double* __restrict__ priors, int A, GridHint hint,
-                                                   RowRec* __restrict__ rows) {
+                                                   RowRec* __restrict__ rows, int* __restrict__ cand_cnt) {
     const int gid = blockIdx.x * WG + threadIdx.x;
     const int row = gid >> 5, sub = gid & 31;
     const bool live = row < total_gt;
@@ -147,26 +149,27 @@ __global__ __launch_bounds__(WG) void k_match_rows(const float4* __restrict__ gt
     if (live && sub == 0) {
         RowRec r;
         r.lx = gc.lx; r.ly = gc.ly; r.hx = gc.hx; r.hy = gc.hy; r.a = gc.a;
-        r.lbm = best * SSD_MARGIN;
+        // Row candidates are collected down to 0.8 x the seed (typically 5-15 columns, never more than ~50): the list then usually holds the runners-up that a row
+        // needs when it loses its best column in phase 1.  No seed (no geometry hint): no list, the row is re-scanned.
+        r.lbm = best * 0.8 * SSD_MARGIN;
         rows[row] = r;
+        cand_cnt[row] = best > 0.0 ? 0 : LIST_CAP + 1;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // K1: the streaming kernel.  grid (chunks, B); thread = one prior column, loops over the image's gt
 // rows whose records arrive through the scalar cache (uniform address).  No division unless
-// inter >= bound*union (bound = min(column bound, row bound)).
+// inter >= bound*union (bound = min(column bound, row bound)).  Exactly evaluated pairs that reach the row
+// bound are appended to the row's candidate list (a handful per row).
 __global__ __launch_bounds__(WG) void k_match_pairs(
     const float4* __restrict__ gt_box, const float* __restrict__ gt_cls, const int* __restrict__ gt_off,
     const RowRec* __restrict__ rows, const double* __restrict__ priors, const float4* __restrict__ enc_zero,
     int A, double thresh, int* __restrict__ out_cls, float4* __restrict__ out_loc,
-    uint8_t* __restrict__ out_mask, int* __restrict__ out_owner, double* __restrict__ part_q,
-    int* __restrict__ part_c, int nchunk) {
-    __shared__ double s_wq[NWAVE][RT];
-    __shared__ int s_wc[NWAVE][RT];
-
+    uint8_t* __restrict__ out_mask, int* __restrict__ out_owner, int* __restrict__ cand_cnt,
+    Cand* __restrict__ cand_list) {
     const int b = blockIdx.y, chunk = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int g0 = gt_off[b];
     const int nt = gt_off[b + 1] - g0;
     const int c = chunk * WG + tid;
@@ -181,53 +184,30 @@ __global__ __launch_bounds__(WG) void k_match_pairs(
     double cbm = thresh * SSD_MARGIN;
     int cbr = -1;
 
-    for (int t0 = 0; t0 < nt; t0 += RT) {
-        const int nr = min(RT, nt - t0);
-        if (t0) __syncthreads();               // previous tile's merge has read the slots
-        RowRec nxt = rows[g0 + t0];                    // uniform -> scalar loads, one row ahead
-        for (int r = 0; r < nr; ++r) {
+    if (nt > 0) {
+        RowRec nxt = rows[g0];                         // uniform -> scalar loads, one row ahead
+        for (int r = 0; r < nt; ++r) {
             const RowRec g = nxt;
-            nxt = rows[g0 + t0 + min(r + 1, nr - 1)];
+            nxt = rows[g0 + min(r + 1, nt - 1)];
             Corner gc;
             gc.lx = g.lx; gc.ly = g.ly; gc.hx = g.hx; gc.hy = g.hy; gc.a = g.a;
             double inter, uni;
             inter_union(gc, pc, inter, uni);
             const double bound = fmin(cbm, g.lbm);
             const bool pass = valid && (inter >= bound * uni);
-            double wbq = 0.0;                  // best row candidate of this wave (uniform)
-            int wbc = INT_MAX;
             if (__ballot(pass)) {              // rare: some lane needs the exact quotient
-                double q = 0.0;
-                bool rowcand = false;
                 if (pass) {
-                    q = inter / uni;
-                    if (q > cbq) { cbq = q; cbr = t0 + r; cbm = q * SSD_MARGIN; }
-                    rowcand = q >= g.lbm;
-                }
-                unsigned long long m = __ballot(rowcand);
-                while (m) {
-                    const int l = __ffsll((long long)m) - 1;
-                    const double ql = readlane_f64(q, l);
-                    const int cl = chunk * WG + (wave << 6) + l;
-                    if (better(ql, cl, wbq, wbc)) { wbq = ql; wbc = cl; }
-                    m &= m - 1;
+                    const double q = inter / uni;
+                    if (q > cbq) { cbq = q; cbr = r; cbm = q * SSD_MARGIN; }
+                    if (g.lbm > 0.0 && q >= g.lbm) {
+                        const int pos = atomicAdd(&cand_cnt[g0 + r], 1);
+                        if (pos < LIST_CAP) {
+                            Cand e; e.q = q; e.c = c; e.pad = 0;
+                            cand_list[(size_t)(g0 + r) * LIST_CAP + pos] = e;
+                        }
+                    }
                 }
             }
-            if (lane == 0) { s_wq[wave][r] = wbq; s_wc[wave][r] = wbc; }
-        }
-        __syncthreads();
-        if (tid < nr) {
-            double bq = 0.0;
-            int bc = INT_MAX;
-#pragma unroll
-            for (int w = 0; w < NWAVE; ++w)
-                if (s_wc[w][tid] != INT_MAX && better(s_wq[w][tid], s_wc[w][tid], bq, bc)) {
-                    bq = s_wq[w][tid];
-                    bc = s_wc[w][tid];
-                }
-            const size_t slot = (size_t)(g0 + t0 + tid) * nchunk + chunk;
-            part_q[slot] = bq;
-            part_c[slot] = bc;
         }
     }
 
@@ -300,8 +280,8 @@ constexpr int P1_LDS_ROWS = 512;               // row state lives in LDS up to t
 // when no two free rows share a best column every row takes its own.
 __global__ __launch_bounds__(WG) void k_match_phase1(
     const float4* __restrict__ gt_box, const float* __restrict__ gt_cls, const int* __restrict__ gt_off,
-    const double* __restrict__ priors, int A, int nchunk, const double* __restrict__ part_q,
-    const int* __restrict__ part_c, double* g_rq, int* g_rc, int* g_rs, int* __restrict__ out_cls,
+    const double* __restrict__ priors, int A, const int* __restrict__ cand_cnt,
+    const Cand* __restrict__ cand_list, double* g_rq, int* g_rc, int* g_rs, int* __restrict__ out_cls,
     float4* __restrict__ out_loc, uint8_t* __restrict__ out_mask, int* __restrict__ out_owner) {
     extern __shared__ unsigned s_bits[];       // 3 A-bit maps: taken | seen | dup
     __shared__ double s_rq[P1_LDS_ROWS];
@@ -328,21 +308,34 @@ __global__ __launch_bounds__(WG) void k_match_phase1(
     if (tid == 0) s_flag = 0;
     __syncthreads();
 
-    // reduce the per-chunk row candidates
-    for (int r = tid; r < nt; r += WG) {
+    // best candidate of every row (lists are unordered: larger q wins, ties to the lower column); 8 lanes per row so
+    // that a row's entries are fetched in one round trip
+    for (int r0 = 0; r0 < nt; r0 += WG / 8) {
+        const int r = r0 + (tid >> 3), sub = tid & 7;
         double bq = 0.0;
         int bc = INT_MAX;
-        const size_t base = (size_t)(g0 + r) * nchunk;
-#pragma unroll 8
-        for (int k = 0; k < nchunk; ++k) {
-            const int c = part_c[base + k];
-            const double q = part_q[base + k];
-            if (c != INT_MAX && better(q, c, bq, bc)) { bq = q; bc = c; }
+        if (r < nt) {
+            const int n = cand_cnt[g0 + r];
+            if (n <= LIST_CAP) {
+                const Cand* L = cand_list + (size_t)(g0 + r) * LIST_CAP;
+                for (int k = sub; k < n; k += 8) {
+                    const Cand e = L[k];
+                    if (better(e.q, e.c, bq, bc)) { bq = e.q; bc = e.c; }
+                }
+            }
         }
-        rq[r] = bq;
-        rc[r] = bc;
-        rs[r] = 1;
-        if (bc == INT_MAX) atomicOr(&s_flag, 2);
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) {
+            const double oq = shfl_xor_f64(bq, off);
+            const int oc = __shfl_xor(bc, off);
+            if (better(oq, oc, bq, bc)) { bq = oq; bc = oc; }
+        }
+        if (r < nt && sub == 0) {
+            rq[r] = bq;
+            rc[r] = bc;
+            rs[r] = 1;
+            if (bc == INT_MAX) atomicOr(&s_flag, 2);
+        }
     }
     __syncthreads();
     if (s_flag & 2) {                          // a row without candidate (never for valid boxes): exact scan
@@ -392,8 +385,16 @@ __global__ __launch_bounds__(WG) void k_match_phase1(
         __syncthreads();
         for (int r = 0; r < nt; ++r) {         // uniform; usually one row
             if (rs[r] != 2) continue;
-            double q; int c;
-            row_scan(gt_corner(gt_box[g0 + r]), priors, A, taken, q, c, s_q, s_c);
+            // the row's list holds every column with IoU >= 0.8 x its seed: if any of them is still free, the best
+            // free one is the row's new maximum (everything outside the list is smaller); else re-scan exactly
+            double q = -1.0; int c = INT_MAX;
+            const int n = cand_cnt[g0 + r];
+            if (n <= LIST_CAP && tid < n) {
+                const Cand e = cand_list[(size_t)(g0 + r) * LIST_CAP + tid];
+                if (!((taken[e.c >> 5] >> (e.c & 31)) & 1u)) { q = e.q; c = e.c; }
+            }
+            wg_argmax(q, c, s_q, s_c);
+            if (c == INT_MAX) row_scan(gt_corner(gt_box[g0 + r]), priors, A, taken, q, c, s_q, s_c);
             __syncthreads();
             if (tid == 0) { rq[r] = q; rc[r] = c; rs[r] = 1; }
             __syncthreads();
@@ -562,11 +563,10 @@ size_t ssd_match_encode_workspace_bytes(int B, int A, int total_gt) {
     (void)B;
     if (A <= 0 || total_gt < 0) return 0;
     const size_t n = (size_t)(total_gt > 0 ? total_gt : 1);
-    const size_t nchunk = (size_t)match_nchunk(A);
     size_t bytes = 0;
     bytes += ssd_align_up(n * sizeof(RowRec), 256);            // row records
-    bytes += ssd_align_up(n * nchunk * sizeof(double), 256);   // part_q
-    bytes += ssd_align_up(n * nchunk * sizeof(int), 256);      // part_c
+    bytes += ssd_align_up(n * LIST_CAP * sizeof(Cand), 256);   // row candidate lists
+    bytes += ssd_align_up(n * sizeof(int), 256);               // list lengths
     bytes += ssd_align_up(n * sizeof(double), 256);            // row_q   (only for n_t > 512)
     bytes += 2 * ssd_align_up(n * sizeof(int), 256);           // row_c, row_state
     return bytes;
@@ -604,8 +604,8 @@ int ssd_match_encode(const float* gt_box, const float* gt_cls, const int32_t* gt
     const size_t n = (size_t)(total_gt > 0 ? total_gt : 1);
     char* p = static_cast<char*>(ws);
     RowRec* rows = reinterpret_cast<RowRec*>(p);   p += ssd_align_up(n * sizeof(RowRec), 256);
-    double* part_q = reinterpret_cast<double*>(p); p += ssd_align_up(n * nchunk * sizeof(double), 256);
-    int* part_c = reinterpret_cast<int*>(p);       p += ssd_align_up(n * nchunk * sizeof(int), 256);
+    Cand* cand_list = reinterpret_cast<Cand*>(p);  p += ssd_align_up(n * LIST_CAP * sizeof(Cand), 256);
+    int* cand_cnt = reinterpret_cast<int*>(p);     p += ssd_align_up(n * sizeof(int), 256);
     double* row_q = reinterpret_cast<double*>(p);  p += ssd_align_up(n * sizeof(double), 256);
     int* row_c = reinterpret_cast<int*>(p);        p += ssd_align_up(n * sizeof(int), 256);
     int* row_state = reinterpret_cast<int*>(p);
@@ -613,18 +613,18 @@ int ssd_match_encode(const float* gt_box, const float* gt_cls, const int32_t* gt
     hipStream_t s = (hipStream_t)stream;
     if (total_gt > 0) {
         hipLaunchKernelGGL(k_match_rows, dim3((total_gt * 32 + WG - 1) / WG), dim3(WG), 0, s,
-                           reinterpret_cast<const float4*>(gt_box), total_gt, priors, A, hint, rows);
+                           reinterpret_cast<const float4*>(gt_box), total_gt, priors, A, hint, rows, cand_cnt);
         if (hipGetLastError() != hipSuccess) return SSD_ERR_LAUNCH;
     }
     hipLaunchKernelGGL(k_match_pairs, dim3(nchunk, B), dim3(WG), 0, s,
                        reinterpret_cast<const float4*>(gt_box), gt_cls, gt_off, rows, priors,
                        reinterpret_cast<const float4*>(enc_zero), A, thresh, out_cls,
-                       reinterpret_cast<float4*>(out_loc), out_mask, out_owner, part_q, part_c, nchunk);
+                       reinterpret_cast<float4*>(out_loc), out_mask, out_owner, cand_cnt, cand_list);
     if (hipGetLastError() != hipSuccess) return SSD_ERR_LAUNCH;
     if (total_gt > 0) {
         hipLaunchKernelGGL(k_match_phase1, dim3(B), dim3(WG), lds_bitmaps, s,
-                           reinterpret_cast<const float4*>(gt_box), gt_cls, gt_off, priors, A, nchunk, part_q,
-                           part_c, row_q, row_c, row_state, out_cls, reinterpret_cast<float4*>(out_loc),
+                           reinterpret_cast<const float4*>(gt_box), gt_cls, gt_off, priors, A, cand_cnt, cand_list,
+                           row_q, row_c, row_state, out_cls, reinterpret_cast<float4*>(out_loc),
                            out_mask, out_owner);
     }
     return ssd_launch_status();

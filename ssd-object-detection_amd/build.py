@@ -44,7 +44,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(OBJ, f[:-4] + ".o")
         objs.append(obj)
         if force or _newer(src, obj, headers):
-            cmd = [HIPCC] + COMMON + PER_FILE.get(f, []) + ["-c", src, "-o", obj]
+            cmd = [HIPCC] + COMMON + PER_FILE.get(f, []) + os.environ.get("SSD_EXTRA_HIPCC_FLAGS", "").split() + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((f, subprocess.Popen(cmd)))

@@ -592,6 +592,263 @@ __global__ __launch_bounds__((BM / (16 * PT)) * (BN >= 128 ? BN / 64 : 2) * 64) 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Implicit GEMM, 256x256x64 tile, 8 waves, eight-phase ping-pong schedule (the wide stride-1/2 layers without
+// parity classes or split-K).  Waves form two groups of four (one wave of each group per SIMD); the groups run
+// half a phase apart, so that on every SIMD one wave is in its MFMA cluster while its partner issues LDS reads and
+// the LDS-DMA of a later tile.  A k-tile is staged as four half-tiles of 16 KB (W0, X0, W1, X1: the 32 channels /
+// 64 pixels of quadrant-row h of every wave); a phase stages ONE half-tile (2 DMA instructions per wave) and
+// multiplies ONE quadrant (64 px x 32 ch x k64 = 16 MFMAs per wave).  Phase p issues half-tile p + 7 of the stream
+// (W0 X0 W1 X1 per tile), i.e. three half-tiles of tile t+2 are still in flight across the barriers when tile t+1
+// is first read: the only wait on the DMA counter is a counted vmcnt(6) in the last phase of a tile.
+//   hazards: a half-tile is read one phase after the wait that retires it (RAW); it is re-staged two phases after
+//   its last LDS read, or one phase after for W0 whose reads are retired (lgkmcnt) before the reading phase's
+//   first barrier (WAR).  Both hold for either group under the half-phase stagger.
+template <int HX, int HW>
+__device__ __forceinline__ void mma_quadrant(f32x4_t (&acc)[4][8], const bf16x8_t (&fx)[4][2], const bf16x8_t (&fw)[2][2]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                acc[HW * 2 + c][HX * 4 + p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[c][ks], fx[p][ks], acc[HW * 2 + c][HX * 4 + p], 0, 0, 0);
+    // hipcc otherwise lets part of the cluster drift below the phase's closing barrier, in among the partner wave's
+    // turn: tie the eight accumulators to this point (no instruction is emitted)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) asm volatile("" : "+v"(acc[HW * 2 + c][HX * 4 + p]));
+}
+
+__device__ __forceinline__ void keep_frags(const bf16x8_t (&fx)[4][2], const bf16x8_t (&fw)[2][2]) {   // dev ablation only
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { asm volatile("" ::"v"(fx[p][0])); asm volatile("" ::"v"(fx[p][1])); }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { asm volatile("" ::"v"(fw[c][0])); asm volatile("" ::"v"(fw[c][1])); }
+}
+
+// ABL: compile-time development ablations (1 no DMA in the loop, 2 no barriers, 4 no MFMA, 16 no fragment reads); 0 in production
+template <int EPI, int ABL>
+__global__ __launch_bounds__(512) void k_conv_igemm_8ph(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ w,
+                                                        ConvGeom g, Epilogue ep) {
+    constexpr int BM = 256, BN = 256;
+    constexpr int HALF = 128 * 128;             // one half-tile image: 128 rows x 64 k bf16
+    constexpr int OFF_W0 = 0, OFF_X0 = HALF, OFF_W1 = 2 * HALF, OFF_X1 = 3 * HALF, BUF = 4 * HALF;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;    // wave tile: pixels wr*128.., channels wc*64..; group = wr
+    const int ntn = (g.N + BN - 1) / BN;
+    const int ntm = (g.M + BM - 1) / BM;
+    const int kx = blockIdx.x >> 3;
+    const int mt = (kx / ntn) * 8 + (blockIdx.x & 7);          // XCD-aware order, as k_conv_igemm_dma
+    if (mt >= ntm) return;
+    const int m0 = mt * BM, n0 = (kx % ntn) * BN;
+
+    // DMA ownership inside a half-tile (16 one-KiB pieces = 8 rows each): wave-instruction i = (wave&1) + 2*((wave>>1) + 4j)
+    const int rl = 2 * (lane >> 4) + ((lane >> 3) & 1);
+    const int slot = (lane & 7) ^ (4 * (wave & 1) + (lane >> 4));
+    int ybase[2][2], xbase[2][2], ibase[2][2];
+    unsigned wrow[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = 8 * ((wave & 1) + 2 * ((wave >> 1) + 4 * j)) + rl;       // row of the half-tile image
+            const int m = m0 + (r >> 6) * 128 + h * 64 + (r & 63);
+            const bool mv = m < g.M;
+            const int mm = mv ? m : 0;
+            const int b = fdiv(mm, g.d_hw);
+            const int rem = mm - b * g.d_hw.d;
+            const int oy = fdiv(rem, g.d_w);
+            const int ox = rem - oy * g.d_w.d;
+            ybase[h][j] = mv ? oy * g.mul - g.pad_t : -(1 << 20);
+            xbase[h][j] = ox * g.mul - g.pad_l;
+            ibase[h][j] = b * g.H * g.W;
+            const int n = n0 + (r >> 5) * 64 + h * 32 + (r & 31);
+            wrow[h][j] = n < g.N ? (unsigned)n * (unsigned)g.ldw : ~0u;
+        }
+    // k state of the activation stream (tap and channel chunk of this lane's slot) and of the weight stream
+    int tap = slot / g.cpt, cc = slot - tap * g.cpt;
+    int kh = tap / g.KW, kw = tap - kh * g.KW;
+    int xq = slot, wq = slot;
+    const int dmask = g.div - 1, dshift = g.div > 1 ? 1 : 0;
+
+    // LDS-DMA through buffer descriptors: 32-bit byte offsets, and a lane whose chunk is padding / out of range gets
+    // an offset beyond the buffer, for which the hardware writes zeros to the lane's LDS slot (no zero block, no branch)
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (unsigned)g.B * g.H * g.W * g.C * 2u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (unsigned)g.N * (unsigned)g.ldw * 2u, 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;
+    auto issue_x = [&](int off, int h) {
+        const bool kvalid = xq < g.nchunks;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = (wave & 1) + 2 * ((wave >> 1) + 4 * j);
+            const int ny = ybase[h][j] + kh, nx = xbase[h][j] + kw;
+            const int iy = ny >> dshift, ix = nx >> dshift;
+            const bool ok = kvalid && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W && (((ny | nx) & dmask) == 0);
+            const unsigned o = ((unsigned)(ibase[h][j] + iy * g.W + ix) * (unsigned)g.C + (unsigned)(cc * 8)) * 2u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)(smem + off + i * 1024), 16, ok ? o : OOB, 0, 0, 0);
+        }
+    };
+    auto advance_x = [&]() {                    // cpt >= 8 (host check): at most one tap boundary per k-tile
+        xq += 8;
+        cc += 8;
+        const bool wrap = cc >= g.cpt;
+        cc -= wrap ? g.cpt : 0;
+        kw += wrap ? 1 : 0;
+        const bool roll = kw == g.KW;
+        kw = roll ? 0 : kw;
+        kh += roll ? 1 : 0;
+    };
+    auto issue_w = [&](int off, int h) {
+        const bool kvalid = wq < g.nchunks;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = (wave & 1) + 2 * ((wave >> 1) + 4 * j);
+            const unsigned o = (wrow[h][j] + (unsigned)(wq * 8)) * 2u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_void*)(smem + off + i * 1024), 16,
+                                                     (kvalid && wrow[h][j] != ~0u) ? o : OOB, 0, 0, 0);
+        }
+    };
+
+    f32x4_t acc[4][8];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) acc[c][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nt = (g.nchunks + 7) >> 3;
+    // prologue: tile 0 completely, W0 X0 W1 of tile 1.  Stages beyond the last tile are issued all the same: every
+    // lane is then out of range, zeros land in a half-tile nobody reads any more, and the DMA count per phase stays 2.
+    issue_w(OFF_W0, 0); issue_x(OFF_X0, 0); issue_w(OFF_W1, 1); issue_x(OFF_X1, 1);
+    wq += 8;
+    advance_x();
+    issue_w(BUF + OFF_W0, 0); issue_x(BUF + OFF_X0, 0); issue_w(BUF + OFF_W1, 1);
+    wq += 8;
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();          // group 1 runs half a phase behind group 0
+
+    const int frow = lane & 15, fk = lane >> 4;
+    const int xf0 = swz(wr * 64 + frow, fk), xf1 = swz(wr * 64 + frow, 4 + fk);     // + p * 2048
+    const int wf0 = swz(wc * 32 + frow, fk), wf1 = swz(wc * 32 + frow, 4 + fk);     // + c * 2048
+    auto ldf = [&](int off) {
+        if constexpr (ABL & 16) return bf16x8_t{};
+        else return *reinterpret_cast<const bf16x8_t*>(smem + off);
+    };
+    bf16x8_t fx[4][2] = {}, fw0[2][2] = {}, fw1[2][2] = {};
+
+#define SSD_PHASE_MMA(HX_, HW_, FW_)                                                                                \
+    if constexpr (!(ABL & 2)) __builtin_amdgcn_s_barrier();                                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    __builtin_amdgcn_s_setprio(1);                                                                                  \
+    if constexpr (!(ABL & 4)) mma_quadrant<HX_, HW_>(acc, fx, FW_);                                                      \
+    else keep_frags(fx, FW_);                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    __builtin_amdgcn_s_setprio(0);                                                                                  \
+    if constexpr (!(ABL & 2)) __builtin_amdgcn_s_barrier();                                                              \
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int t = 0; t < nt; ++t) {
+        const int cb = (t & 1) * BUF, nb = BUF - cb;
+        // ---- phase 0: quadrant (X0, W0); stage X1 of tile t+1
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { fw0[c][0] = ldf(cb + OFF_W0 + wf0 + c * 2048); fw0[c][1] = ldf(cb + OFF_W0 + wf1 + c * 2048); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { fx[p][0] = ldf(cb + OFF_X0 + xf0 + p * 2048); fx[p][1] = ldf(cb + OFF_X0 + xf1 + p * 2048); }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");      // the W0 reads are done: W0 may be re-staged next phase
+        if constexpr (!(ABL & 1)) issue_x(nb + OFF_X1, 1);
+        advance_x();
+        SSD_PHASE_MMA(0, 0, fw0)
+        // ---- phase 1: quadrant (X0, W1); stage W0 of tile t+2
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { fw1[c][0] = ldf(cb + OFF_W1 + wf0 + c * 2048); fw1[c][1] = ldf(cb + OFF_W1 + wf1 + c * 2048); }
+        if constexpr (!(ABL & 1)) issue_w(cb + OFF_W0, 0);
+        SSD_PHASE_MMA(0, 1, fw1)
+        // ---- phase 2: quadrant (X1, W1); stage X0 of tile t+2
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { fx[p][0] = ldf(cb + OFF_X1 + xf0 + p * 2048); fx[p][1] = ldf(cb + OFF_X1 + xf1 + p * 2048); }
+        if constexpr (!(ABL & 1)) issue_x(cb + OFF_X0, 0);
+        SSD_PHASE_MMA(1, 1, fw1)
+        // ---- phase 3: quadrant (X1, W0); stage W1 of tile t+2; all of tile t+1 has landed once only the last three
+        // half-tiles (6 DMA instructions of this wave) are still in flight
+        if constexpr (!(ABL & 1)) issue_w(cb + OFF_W1, 1);
+        wq += 8;
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        SSD_PHASE_MMA(1, 0, fw0)
+    }
+#undef SSD_PHASE_MMA
+    if (wr == 0) __builtin_amdgcn_s_barrier();          // balance the stagger
+
+    // Epilogue.  Plain layouts go through LDS (free now) so that global stores are whole 16-byte chunks of contiguous
+    // rows: the direct accumulator layout gives 8-byte stores in 32-byte runs, and with one workgroup per CU nothing
+    // hides that store tail.
+    bool staged = false;
+    if constexpr (EPI == EPI_FWD) staged = (g.N & 7) == 0 && (ep.ldo & 7) == 0;
+    if constexpr (EPI == EPI_DGRAD) staged = (g.N & 7) == 0 && (ep.ldo & 7) == 0 && !ep.accumulate;
+    if (staged) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the (all-zero) stages issued past the last tile
+        __builtin_amdgcn_s_barrier();
+        // tile image [256 px][256 ch] bf16, 512-byte rows, 16-byte chunk index XORed with (row & 31)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int n = n0 + wc * 64 + c * 16 + (lane >> 4) * 4;
+            float b4[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (EPI == EPI_FWD) { if (n < g.N) load_bias4(ep, n, g.N, true, b4); }
+            const int chunk = wc * 8 + c * 2 + (lane >> 5);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int row = wr * 128 + p * 16 + (lane & 15);
+                float v[4] = {acc[c][p][0] + b4[0], acc[c][p][1] + b4[1], acc[c][p][2] + b4[2], acc[c][p][3] + b4[3]};
+                if constexpr (EPI == EPI_FWD) {
+                    if (ep.relu) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                    }
+                }
+                *reinterpret_cast<uint2*>(smem + row * 512 + ((chunk ^ (row & 31)) << 4) + ((lane >> 4) & 1) * 8) =
+                    make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+            }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int idx = it * 512 + tid;
+            const int row = idx >> 5, ch = idx & 31;
+            const int m = m0 + row, n = n0 + ch * 8;
+            if (m >= g.M || n >= g.N) continue;
+            uint4 v = *reinterpret_cast<const uint4*>(smem + row * 512 + ((ch ^ (row & 31)) << 4));
+            const long long o = (long long)m * ep.ldo + n;
+            if constexpr (EPI == EPI_DGRAD) {
+                if (ep.mask_src) {                            // ReLU backward: zero where the forward activation was <= 0
+                    const uint4 mk = *reinterpret_cast<const uint4*>(ep.mask_src + o);
+                    auto gate = [](unsigned val, unsigned m2) {
+                        if (!(__uint_as_float(m2 << 16) > 0.f)) val &= 0xffff0000u;
+                        if (!(__uint_as_float(m2 & 0xffff0000u) > 0.f)) val &= 0x0000ffffu;
+                        return val;
+                    };
+                    v.x = gate(v.x, mk.x); v.y = gate(v.y, mk.y); v.z = gate(v.z, mk.z); v.w = gate(v.w, mk.w);
+                }
+            }
+            *reinterpret_cast<uint4*>(ep.out + o) = v;
+        }
+        return;
+    }
+    int mrow[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int m = m0 + wr * 128 + p * 16 + (lane & 15);
+        mrow[p] = m < g.M ? m : -1;
+    }
+    conv_epilogue_rows<EPI, 4, 8>(acc, g, ep, mrow, n0 + wc * 64, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 convolution with an LDS-resident input patch (forward, and data gradient with the
 // transposed weights).  A workgroup owns a 16x16 block of output pixels of one image and BN output channels.
 // Per 64-channel chunk of the input, the 18x18-pixel halo patch is brought into LDS ONCE (LDS-DMA) and all nine
@@ -1408,11 +1665,11 @@ ConvGeom make_geom(int B, int H, int W, int C, int Ho, int Wo, int N, int KH, in
     return g;
 }
 
-int igemm_variant() {                       // SSD_CONV_VARIANT=0: register-staged kernel, 1 (default): LDS-DMA kernel
+int igemm_variant() {                       // SSD_CONV_VARIANT=0: register-staged kernel, 1: LDS-DMA kernels, 2 (default): + 8-phase 256x256
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("SSD_CONV_VARIANT");
-        v = e ? atoi(e) : 1;
+        v = e ? atoi(e) : 2;
     }
     return v;
 }
@@ -1496,7 +1753,37 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
             if (g.s2) { ntm_ = 0; for (int c_ = 0; c_ < 4; ++c_) ntm_ += (unsigned)((g.cls_n[c_] + BM_ - 1) / BM_); } \
             hipLaunchKernelGGL(kern_, dim3(8 * ntn_ * ((ntm_ + 7) / 8), ksplit), dim3(NT_), lds_, s, xp, wp, g, ep); \
         } while (0)
-        if (bm == 256 && bn == 256) SSD_LAUNCH_DMA(256, 256);
+        if (bm == 256 && bn == 256 && igemm_variant() >= 2 && !g.s2 && ksplit == 1 && g.cpt >= 8 &&
+            (long long)g.B * g.H * g.W * g.C < (1ll << 31) - 16 && (long long)g.N * g.ldw < (1ll << 31) - 16) {
+            const unsigned ntm = (unsigned)((g.M + 255) / 256), ntn = (unsigned)((g.N + 255) / 256);
+#define SSD_LAUNCH_8PH(ABL_)                                                                                        \
+            do {                                                                                                    \
+                auto kern = k_conv_igemm_8ph<EPI, ABL_>;                                                            \
+                static bool set = false;                                                                            \
+                if (!set) {                                                                                         \
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 131072) != hipSuccess) \
+                        return SSD_ERR_LAUNCH;                                                                      \
+                    set = true;                                                                                     \
+                }                                                                                                   \
+                hipLaunchKernelGGL(kern, dim3(8 * ntn * ((ntm + 7) / 8)), dim3(512), 131072, s, xp, wp, g, ep);      \
+            } while (0)
+#ifdef SSD_DEV_ABLATE
+            if constexpr (EPI == EPI_FWD) {
+                switch (g.ablate) {
+                    case 1: SSD_LAUNCH_8PH(1); break;
+                    case 4: SSD_LAUNCH_8PH(4); break;
+                    case 5: SSD_LAUNCH_8PH(5); break;
+                    case 20: SSD_LAUNCH_8PH(20); break;
+                    case 21: SSD_LAUNCH_8PH(21); break;
+                    case 23: SSD_LAUNCH_8PH(23); break;
+                    default: SSD_LAUNCH_8PH(0); break;
+                }
+            } else
+#endif
+            SSD_LAUNCH_8PH(0);
+#undef SSD_LAUNCH_8PH
+        }
+        else if (bm == 256 && bn == 256) SSD_LAUNCH_DMA(256, 256);
         else if (bm == 256 && bn == 128) SSD_LAUNCH_DMA(256, 128);
         else if (bm == 256 && bn == 64) SSD_LAUNCH_DMA(256, 64);
         else if (bn == 64) SSD_LAUNCH_DMA(128, 64);

@@ -38,22 +38,41 @@ for r in rows[i:]:
     key = r['Kernel_Name'].split('(')[0][-40:]
     bt.setdefault(key, 0.0); bt[key] += dur(r)
 for k, v in bt.items(): print("%-44s %.2f ms" % (k, v / 1e3))
-# backward detail: heads first (6x: wgrad, reduce, reduce, dgrad), then trunk reversed
+# backward detail: per layer "wgrad [reduce] dgrad [finalize]" in engine.backward order
 j = i
 print("---- backward detail")
-def take():
+def kind(r):
+    n = r['Kernel_Name']
+    if 'reduce' in n: return 'reduce'
+    if 'wgrad' in n: return 'wgrad'
+    if 'finalize' in n: return 'finalize'
+    return 'dgrad'
+def grid(r): return r['Grid_Size_X'] + 'x' + r['Grid_Size_Y'] + 'x' + r['Grid_Size_Z']
+def short(r): return r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
+def layer(label, fl, has_dgrad):
     global j
-    r = rows[j]; j += 1; return r
+    w = rows[j]; j += 1
+    assert kind(w) == 'wgrad', (label, w['Kernel_Name'])
+    tw = dur(w)
+    while j < len(rows) and kind(rows[j]) == 'reduce':
+        tw += dur(rows[j]); j += 1
+    line = "%-30s wgrad %7.1f us %7.1f TF/s %-26s %-16s" % (label, tw, fl / tw / 1e6, short(w)[:26], grid(w))
+    t = tw
+    if has_dgrad:
+        dg = rows[j]; j += 1
+        assert kind(dg) == 'dgrad', (label, dg['Kernel_Name'])
+        td = dur(dg)
+        while j < len(rows) and kind(rows[j]) == 'finalize':
+            td += dur(rows[j]); j += 1
+        line += " | dgrad %7.1f us %7.1f TF/s %-30s %s" % (td, fl / td / 1e6, short(dg)[:30], grid(dg))
+        t += td
+    print(line)
+    return t
+tb = 0
 for lvl, (h, c, no) in enumerate(heads):
-    w = take(); take(); take(); dg = take()
-    fl = 2.0 * B * h * h * no * 9 * c
-    print("head%d wgrad %8.1f us %7.1f TF/s (grid %sx%sx%s) | dgrad %8.1f us %7.1f TF/s" % (lvl, dur(w), fl / dur(w) / 1e6, w['Grid_Size_X'], w['Grid_Size_Y'], w['Grid_Size_Z'], dur(dg), fl / dur(dg) / 1e6))
+    tb += layer("head%d %dx%d %d->%d" % (lvl, h, h, c, no), 2.0 * B * h * h * no * 9 * c, True)
 for ci in range(len(convs) - 1, -1, -1):
     n = convs[ci]
     fl = 2.0 * B * n[5] * n[5] * n[2] * n[3] * n[3] * n[1]
-    w = take(); take(); take()
-    line = "c%-2d %dx%d %d->%d k%d wgrad %8.1f us %7.1f TF/s (grid %sx%sx%s)" % (ci, n[5], n[5], n[1], n[2], n[3], dur(w), fl / dur(w) / 1e6, w['Grid_Size_X'], w['Grid_Size_Y'], w['Grid_Size_Z'])
-    if ci > 0:
-        dg = take()
-        line += " | dgrad %8.1f us %7.1f TF/s" % (dur(dg), fl / dur(dg) / 1e6)
-    print(line)
+    tb += layer("c%-2d %dx%d %d->%d k%d" % (ci, n[5], n[5], n[1], n[2], n[3]), fl, ci > 0)
+print("backward conv total %.2f ms" % (tb / 1e3))

@@ -223,6 +223,11 @@ int ssd_adam_step(float* param, const float* grad, float* m, float* v, void* par
 int ssd_sgd_step(float* param, const float* grad, void* param_bf16, long long n, const int32_t* block_tensor,
                  const float* scale, float grad_scale, float lr, void* stream);
 
+/* Development only (no reference counterpart): override one of the library's tuning knobs (the SSD_* environment
+ * variables documented in DESIGN.md, e.g. "SSD_CONV_VARIANT") at run time, for A/B timing of kernel variants inside one
+ * process.  Results never depend on a knob; SSD_ERR_VALUE for an unknown name. */
+int ssd_dev_knob(const char* name, int value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,7 @@ _SIGNATURES = {
     "ssd_grad_accumulate": (ctypes.c_int, [VP, VP, ctypes.c_longlong, VP, VP, ctypes.c_int, VP]),
     "ssd_adam_step": (ctypes.c_int, [VP, VP, VP, VP, VP, ctypes.c_longlong, VP, VP] + [ctypes.c_float] * 5 + [VP]),
     "ssd_sgd_step": (ctypes.c_int, [VP, VP, VP, ctypes.c_longlong, VP, VP, ctypes.c_float, ctypes.c_float, VP]),
+    "ssd_dev_knob": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     "ssd_loss_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "ssd_loss_fwd_bwd": (ctypes.c_int, [VP, VP, ctypes.c_int, VP, VP, VP, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_float, VP, VP, VP, VP, ctypes.c_size_t, VP]),

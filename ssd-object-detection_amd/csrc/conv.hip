@@ -23,6 +23,8 @@
 //                  (grid.z); fp32 partial slabs are summed in fixed order (deterministic) by
 //                  k_wgrad_reduce.  The bias gradient rides along as an extra MFMA against a B fragment
 //                  of ones.
+#include <cstring>
+#include <type_traits>
 #include "common.h"
 #include <hip/hip_bf16.h>
 #include <stdlib.h>
@@ -219,6 +221,90 @@ __device__ __forceinline__ void conv_epilogue_rows(f32x4_t (&acc)[CT][PT], const
             if (m < 0) continue;
             float v[4] = {acc[c][p][0] + bias4[0], acc[c][p][1] + bias4[1], acc[c][p][2] + bias4[2], acc[c][p][3] + bias4[3]};
             epi_store<EPI>(v, m, n, full, g, ep);
+        }
+    }
+}
+
+// Epilogue through LDS: the accumulator layout (a lane holds 4 channels of 16 different pixels) gives 8-byte stores in
+// 32-byte runs (2-byte scattered stores for the head layout); staging the [BM px][BN ch] bf16 tile in LDS first turns
+// them into whole 16-byte chunks of contiguous rows (heads: 64 consecutive elements per wave-instruction).
+// Tile image: BN*2-byte rows, 16-byte chunk index XORed with the row so that both the 8-byte fragment writes and the
+// row-wise reads are (nearly) conflict-free.  Caller guarantees: all waves are past their last LDS read and no LDS-DMA
+// is in flight.  row_to_m(row) -> flat output pixel or -1.
+template <int EPI>
+__device__ __forceinline__ bool staged_ok(const ConvGeom& g, const Epilogue& ep) {
+    if (ep.slab) return false;
+    if constexpr (EPI == EPI_FWD) return (g.N & 7) == 0 && (ep.ldo & 7) == 0;
+    if constexpr (EPI == EPI_DGRAD) return (g.N & 7) == 0 && (ep.ldo & 7) == 0 && !ep.accumulate;
+    return true;                                // EPI_HEAD
+}
+
+template <int EPI, int BM, int BN, int CT, int PT, int NT, typename RowMap>
+__device__ __forceinline__ void staged_epilogue(f32x4_t (&acc)[CT][PT], char* smem, const ConvGeom& g, const Epilogue& ep,
+                                                int n0, int wrow0, int wcol0, int tid, RowMap row_to_m) {
+    constexpr int CPR = BN / 8;                 // 16-byte chunks per tile row
+    const int lane = tid & 63;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int col = wcol0 + c * 16 + (lane >> 4) * 4;
+        const int n = n0 + col;
+        float b4[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (EPI != EPI_DGRAD) { if (n < g.N) load_bias4(ep, n, g.N, n + 3 < g.N, b4); }
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            const int row = wrow0 + p * 16 + (lane & 15);
+            float v[4] = {acc[c][p][0] + b4[0], acc[c][p][1] + b4[1], acc[c][p][2] + b4[2], acc[c][p][3] + b4[3]};
+            if constexpr (EPI == EPI_FWD) {
+                if (ep.relu) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                }
+            }
+            *reinterpret_cast<uint2*>(smem + row * (BN * 2) + ((((col >> 3) ^ row) & (CPR - 1)) << 4) + (col & 4) * 2) =
+                make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+        }
+    }
+    __syncthreads();
+    if constexpr (EPI == EPI_HEAD) {
+        // element-wise, 64 consecutive channels of one pixel per wave-instruction
+        constexpr int ITER = BM * BN / NT;
+        for (int it = 0; it < ITER; ++it) {
+            const int idx = it * NT + tid;
+            const int row = idx / BN, col = idx - row * BN;
+            const int n = n0 + col;
+            const int m = row_to_m(row);
+            if (m < 0 || n >= ep.n_loc + ep.n_conf) continue;
+            const bf16_raw val = *reinterpret_cast<const bf16_raw*>(smem + row * (BN * 2) + ((((col >> 3) ^ row) & (CPR - 1)) << 4) + (col & 7) * 2);
+            const int b = fdiv(m, g.d_hw);
+            const int pix = m - b * g.d_hw.d;
+            const long long anchor0 = (long long)b * ep.anchors_total + ep.level_off + (long long)pix * ep.per_cell;
+            if (n < ep.n_loc) ep.loc[anchor0 * 4 + n] = val;
+            else ep.conf[anchor0 * ep.classes + (n - ep.n_loc)] = val;
+        }
+    } else {
+        constexpr int ITER = BM * CPR / NT;
+#pragma unroll 4
+        for (int it = 0; it < ITER; ++it) {
+            const int idx = it * NT + tid;
+            const int row = idx / CPR, ch = idx - row * CPR;
+            const int n = n0 + ch * 8;
+            const int m = row_to_m(row);
+            if (m < 0 || n >= g.N) continue;
+            uint4 v = *reinterpret_cast<const uint4*>(smem + row * (BN * 2) + (((ch ^ row) & (CPR - 1)) << 4));
+            const long long o = (long long)m * ep.ldo + n;
+            if constexpr (EPI == EPI_DGRAD) {
+                if (ep.mask_src) {                            // ReLU backward: zero where the forward activation was <= 0
+                    const uint4 mk = *reinterpret_cast<const uint4*>(ep.mask_src + o);
+                    auto gate = [](unsigned val, unsigned m2) {
+                        if (!(__uint_as_float(m2 << 16) > 0.f)) val &= 0xffff0000u;
+                        if (!(__uint_as_float(m2 & 0xffff0000u) > 0.f)) val &= 0x0000ffffu;
+                        return val;
+                    };
+                    v.x = gate(v.x, mk.x); v.y = gate(v.y, mk.y); v.z = gate(v.z, mk.z); v.w = gate(v.w, mk.w);
+                }
+            }
+            *reinterpret_cast<uint4*>(ep.out + o) = v;
         }
     }
 }
@@ -577,6 +663,18 @@ __global__ __launch_bounds__((BM / (16 * PT)) * (BN >= 128 ? BN / 64 : 2) * 64) 
             }
         }
     }
+    if (staged_ok<EPI>(g, ep) && !(g.ablate & 8)) {
+        auto row_to_m = [&](int row) {
+            const int m = m0 + row;
+            if (m >= cls_count) return -1;
+            if (!g.s2) return m;
+            int b, oy, ox;
+            decode(m, b, oy, ox);
+            return (b * g.Ho + oy) * g.Wo + ox;
+        };
+        staged_epilogue<EPI, BM, BN, CT, PT, NW * 64>(acc, smem, g, ep, n0, wave_m * (16 * PT), wave_n * (16 * CT), tid, row_to_m);
+        return;
+    }
     int mrow[PT];
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
@@ -785,58 +883,11 @@ __global__ __launch_bounds__(512) void k_conv_igemm_8ph(const bf16_raw* __restri
 #undef SSD_PHASE_MMA
     if (wr == 0) __builtin_amdgcn_s_barrier();          // balance the stagger
 
-    // Epilogue.  Plain layouts go through LDS (free now) so that global stores are whole 16-byte chunks of contiguous
-    // rows: the direct accumulator layout gives 8-byte stores in 32-byte runs, and with one workgroup per CU nothing
-    // hides that store tail.
-    bool staged = false;
-    if constexpr (EPI == EPI_FWD) staged = (g.N & 7) == 0 && (ep.ldo & 7) == 0;
-    if constexpr (EPI == EPI_DGRAD) staged = (g.N & 7) == 0 && (ep.ldo & 7) == 0 && !ep.accumulate;
-    if (staged) {
+    // Epilogue through LDS (free now): with one workgroup per CU nothing would hide a scattered store tail
+    if (staged_ok<EPI>(g, ep) && !(g.ablate & 8)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the (all-zero) stages issued past the last tile
-        __builtin_amdgcn_s_barrier();
-        // tile image [256 px][256 ch] bf16, 512-byte rows, 16-byte chunk index XORed with (row & 31)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int n = n0 + wc * 64 + c * 16 + (lane >> 4) * 4;
-            float b4[4] = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (EPI == EPI_FWD) { if (n < g.N) load_bias4(ep, n, g.N, true, b4); }
-            const int chunk = wc * 8 + c * 2 + (lane >> 5);
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const int row = wr * 128 + p * 16 + (lane & 15);
-                float v[4] = {acc[c][p][0] + b4[0], acc[c][p][1] + b4[1], acc[c][p][2] + b4[2], acc[c][p][3] + b4[3]};
-                if constexpr (EPI == EPI_FWD) {
-                    if (ep.relu) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-                    }
-                }
-                *reinterpret_cast<uint2*>(smem + row * 512 + ((chunk ^ (row & 31)) << 4) + ((lane >> 4) & 1) * 8) =
-                    make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
-            }
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
-            const int idx = it * 512 + tid;
-            const int row = idx >> 5, ch = idx & 31;
-            const int m = m0 + row, n = n0 + ch * 8;
-            if (m >= g.M || n >= g.N) continue;
-            uint4 v = *reinterpret_cast<const uint4*>(smem + row * 512 + ((ch ^ (row & 31)) << 4));
-            const long long o = (long long)m * ep.ldo + n;
-            if constexpr (EPI == EPI_DGRAD) {
-                if (ep.mask_src) {                            // ReLU backward: zero where the forward activation was <= 0
-                    const uint4 mk = *reinterpret_cast<const uint4*>(ep.mask_src + o);
-                    auto gate = [](unsigned val, unsigned m2) {
-                        if (!(__uint_as_float(m2 << 16) > 0.f)) val &= 0xffff0000u;
-                        if (!(__uint_as_float(m2 & 0xffff0000u) > 0.f)) val &= 0x0000ffffu;
-                        return val;
-                    };
-                    v.x = gate(v.x, mk.x); v.y = gate(v.y, mk.y); v.z = gate(v.z, mk.z); v.w = gate(v.w, mk.w);
-                }
-            }
-            *reinterpret_cast<uint4*>(ep.out + o) = v;
-        }
+        auto row_to_m = [&](int row) { const int m = m0 + row; return m < g.M ? m : -1; };
+        staged_epilogue<EPI, 256, 256, 4, 8, 512>(acc, smem, g, ep, n0, wr * 128, wc * 64, tid, row_to_m);
         return;
     }
     int mrow[8];
@@ -1324,17 +1375,22 @@ __global__ __launch_bounds__((BMO / (16 * AT)) * (BNC / 64) * 64) void k_conv_wg
 // Weight gradient of a 3x3 / stride 1 / pad 1 convolution with LDS-resident tiles ("patch" form).
 // A workgroup owns 64 output channels x 64 input channels (one channel chunk) x all nine taps, and walks a range
 // of 16x16 output-pixel blocks.  Per block it brings in the dY tile [256 px][64 co] and the 18x18 halo patch of X
-// [324 px][64 ci] ONCE (LDS-DMA, double-buffered); wave t (of nine) accumulates tap t:
-//     dW[co][t][ci] += sum_px dY[px][co] * X[px + shift(t)][ci]
-// with both operands fetched by transposing LDS reads (the patch at tap-shifted addresses).  ~128 MACs per byte
-// brought into the CU, versus 32 for the generic 128x128 tile that re-stages X for every tap.
+// [324 px][64 ci] ONCE (LDS-DMA, double-buffered) and accumulates
+//     dW[co][t][ci] += sum_px dY[px][co] * X[px + shift(t)][ci]          for the nine taps t
+// with both operands fetched by transposing LDS reads (the patch at tap-shifted addresses).  The 144 accumulator
+// tiles (4 co-tiles x 9 taps x 4 ci-tiles) are dealt to eight waves, 18 each (2 co-tiles x 9 taps x 1 ci-tile), so
+// that all four SIMDs carry the same MFMA load (one wave per tap left one SIMD with 3 waves and the others with 2).
+// ~128 MACs per byte brought into the CU, versus 32 for the generic 128x128 tile that re-stages X for every tap.
 constexpr int WP_DY_BYTES = 256 * 128;                     // 32 KiB
 constexpr int WP_BUF = WP_DY_BYTES + PATCH_BYTES;          // one buffer: dY tile + X patch
 
-// 32-byte column group permutation of a 128-byte pixel row: conflict-free for the 4+4 rows of a half-wave
-__device__ __forceinline__ int wp_key(int px) { return (px & 3) ^ (((px >> 3) & 1) << 1); }
+// 32-byte column group permutation of a 128-byte pixel row.  A half-wave of a transposing read touches 8 CONSECUTIVE
+// pixel rows (any alignment: taps shift them); (p & 1, (p >> 1) & 3) then takes all eight values, i.e. the eight
+// 32-byte pieces fall into eight different bank groups.  The key has period 8 in p, which is what lets the reader
+// keep eight per-lane base addresses and reach every (k-step, tap, half) with an immediate offset.
+__device__ __forceinline__ int wp_key(int px) { return (px >> 1) & 3; }
 
-__global__ __launch_bounds__(576) void k_conv3x3_wgrad_patch(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ dy,
+__global__ __launch_bounds__(512) void k_conv3x3_wgrad_patch(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ dy,
                                                              float* __restrict__ slab_w, float* __restrict__ slab_b,
                                                              ConvGeom g, int tiles_x, int tiles_y, int tiles_per_split,
                                                              int nsplit, int cout, int single_buf) {
@@ -1344,8 +1400,10 @@ __global__ __launch_bounds__(576) void k_conv3x3_wgrad_patch(const bf16_raw* __r
     auto s_px = [&](int buf) { return smem + buf * WP_BUF + WP_DY_BYTES; };
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0..8 = tap
-    const int kh = wave / 3, kw = wave - 3 * kh;
+    // eight waves (two per SIMD, equal work): wave w owns output-channel tiles {2(w&1), 2(w&1)+1} x input-channel
+    // tile (w>>1) x all nine taps = 18 accumulator tiles
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ap = wave & 1, ct = wave >> 1;
     const int nchunk = g.C >> 6, cotiles = (cout + 63) >> 6;
     int id = blockIdx.x;
     const int chunk = id % nchunk; id /= nchunk;
@@ -1355,7 +1413,7 @@ __global__ __launch_bounds__(576) void k_conv3x3_wgrad_patch(const bf16_raw* __r
     const int ntiles = g.B * tiles_x * tiles_y;
     const int t_begin = split * tiles_per_split, t_end = min(ntiles, t_begin + tiles_per_split);
 
-    // DMA ownership: dY tile = 32 instructions, patch = 41; instruction i of each goes to wave i % 9
+    // DMA ownership: dY tile = 32 instructions, patch = 41; instruction i of each goes to wave i % 8
     auto issue_dma = [&](int t, int buf) {
         int r = t;
         const int tx = r % tiles_x; r /= tiles_x;
@@ -1364,8 +1422,8 @@ __global__ __launch_bounds__(576) void k_conv3x3_wgrad_patch(const bf16_raw* __r
         const int y0 = ty * 16, x0 = tx * 16;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int i = wave + 9 * j;
-            if (i < 32) {                                   // 8 pixels x 128 B per instruction
+            const int i = wave + 8 * j;
+            {                                               // 8 pixels x 128 B per instruction
                 const int px = 8 * i + (lane >> 3), sl = lane & 7;
                 const int c16 = (((sl >> 1) ^ wp_key(px)) << 1) | (sl & 1);
                 const int y = y0 + (px >> 4), xx = x0 + (px & 15);
@@ -1377,8 +1435,8 @@ __global__ __launch_bounds__(576) void k_conv3x3_wgrad_patch(const bf16_raw* __r
             }
         }
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int i = wave + 9 * j;
+        for (int j = 0; j < 6; ++j) {
+            const int i = wave + 8 * j;
             if (i < PATCH_INSTR) {
                 const int pp = 8 * i + (lane >> 3), sl = lane & 7;
                 const int c16 = (((sl >> 1) ^ wp_key(pp)) << 1) | (sl & 1);
@@ -1392,15 +1450,15 @@ __global__ __launch_bounds__(576) void k_conv3x3_wgrad_patch(const bf16_raw* __r
         }
     };
 
-    f32x4_t acc[4][4];
-    f32x4_t accb[4];
+    f32x4_t acc[2][9];
+    f32x4_t accb[2];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
+    for (int a = 0; a < 2; ++a) {
         accb[a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[a][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int t9 = 0; t9 < 9; ++t9) acc[a][t9] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
-    const bool do_bias = slab_b != nullptr && chunk == 0 && wave == 4;
+    const bool do_bias = slab_b != nullptr && chunk == 0 && ct == 0;
     bf16x8_t ones;
 #pragma unroll
     for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
@@ -1408,72 +1466,122 @@ __global__ __launch_bounds__(576) void k_conv3x3_wgrad_patch(const bf16_raw* __r
     // single_buf: one LDS buffer (74 KB) so that TWO workgroups share a CU and hide each other's DMA latency;
     // otherwise two buffers in one workgroup (150 KB), next block's DMA in flight during this block's MFMAs
     if (t_begin < t_end) issue_dma(t_begin, 0);
+    // MFMA k index <-> block pixel: k-step ks covers block rows 2ks, 2ks+1; within it lane group gq and `half` select
+    //   row 2ks + (gq>>1), column 8*half + 4*(gq&1) + (li>>2)
+    // so that the 8 rows of a half-wave instruction are consecutive pixels.  All address arithmetic is hoisted: the dY
+    // row of a lane is base + immediate, and a patch row is one of eight per-lane bases (pixel offset mod 8) + immediate.
     const int gq = lane >> 4, li = lane & 15;
-    for (int t = t_begin; t < t_end; ++t) {
-        const int cur = single_buf ? 0 : (t - t_begin) & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (!single_buf && t + 1 < t_end) issue_dma(t + 1, cur ^ 1);
-        const char* pdy = s_dy(cur);
-        const char* ppx = s_px(cur);
-#pragma unroll 2
-        for (int ks = 0; ks < 8; ++ks) {                    // 32 pixels (two block rows) per k-step
-            bf16x8_t fa[4], fb[4];
+    int abase[2];
+    {
+        const int kk0 = (gq >> 1) * 16 + (gq & 1) * 4 + (li >> 2);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) abase[a] = kk0 * 128 + (((2 * ap + a) ^ wp_key(kk0)) << 5) + (li & 3) * 8;
+    }
+    int gbase[8];
+    {
+        const int p0 = (gq >> 1) * PATCH_W + (gq & 1) * 4 + (li >> 2);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) gbase[r] = WP_DY_BYTES + (p0 + r) * 128 + ((ct ^ wp_key(p0 + r)) << 5) + (li & 3) * 8;
+    }
+    typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
+    // fragments of one k-step: 4 dY reads + 18 patch reads (all with immediate offsets)
+    struct Frag { bf16x8_t fa[2]; bf16x8_t fb[9]; };
+    auto load_frag = [&](Frag& f, const int (&ab)[2], const int (&gb)[8], auto ks_tag) {
+        constexpr int ks = decltype(ks_tag)::value;
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+                reinterpret_cast<s16x4_t*>(&f.fa[a])[half] =
+                    __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + ab[a] + ks * 4096 + half * 1024));
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9)
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                const int kk = ks * 32 + gq * 8 + half * 4 + (li >> 2);      // pixel of the block = MFMA k index
-                const int ka = wp_key(kk);
-                const int pp = ((kk >> 4) + kh) * PATCH_W + (kk & 15) + kw;  // tap-shifted patch pixel
-                const int kb = wp_key(pp);
+                constexpr int dummy = 0; (void)dummy;
+                const int ctap = ks * 2 * PATCH_W + half * 8 + (t9 / 3) * PATCH_W + (t9 % 3);       // compile-time pixel offset
+                reinterpret_cast<s16x4_t*>(&f.fb[t9])[half] =
+                    __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + gb[ctap & 7] + (ctap >> 3) * 1024));
+            }
+    };
+    // the block loop exists twice (with / without the bias MFMAs) so that its body has no branch: the eight k-steps of
+    // a block are one basic block, software-pipelined by hand (fragments of k-step ks+1 are read during the MFMAs of ks)
+    auto run = [&](auto bias_tag) {
+        constexpr bool BIAS = decltype(bias_tag)::value;
+        for (int t = t_begin; t < t_end; ++t) {
+            const int cur = single_buf ? 0 : (t - t_begin) & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (!single_buf && t + 1 < t_end) issue_dma(t + 1, cur ^ 1);
+            const int boff = cur * WP_BUF;
+            int ab[2], gb[8];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const char* ptr = pdy + kk * 128 + ((a ^ ka) << 5) + (li & 3) * 8;
-                    reinterpret_cast<s16x4_t*>(&fa[a])[half] =
-                        __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(ptr));
+            for (int a = 0; a < 2; ++a) ab[a] = abase[a] + boff;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) gb[r] = gbase[r] + boff;
+            Frag f0, f1;
+            auto mma = [&](const Frag& f) {
+#pragma unroll
+                for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+                        acc[a][t9] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.fa[a], f.fb[t9], acc[a][t9], 0, 0, 0);
+                if constexpr (BIAS) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.fa[a], ones, accb[a], 0, 0, 0);
+                }
+            };
+            // interleave: one MFMA, then one LDS read of the next k-step (22 reads over 18-20 MFMAs)
+            auto weave = [&]() {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 }
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const char* ptr = ppx + pp * 128 + ((c ^ kb) << 5) + (li & 3) * 8;
-                    reinterpret_cast<s16x4_t*>(&fb[c])[half] =
-                        __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(ptr));
+                for (int i = 0; i < 14; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
-            }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[c], acc[a][c], 0, 0, 0);
-            if (do_bias) {
-#pragma unroll
-                for (int a = 0; a < 4; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], ones, accb[a], 0, 0, 0);
+                if constexpr (BIAS) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            };
+            load_frag(f0, ab, gb, std::integral_constant<int, 0>{});
+            load_frag(f1, ab, gb, std::integral_constant<int, 1>{}); mma(f0); weave();
+            load_frag(f0, ab, gb, std::integral_constant<int, 2>{}); mma(f1); weave();
+            load_frag(f1, ab, gb, std::integral_constant<int, 3>{}); mma(f0); weave();
+            load_frag(f0, ab, gb, std::integral_constant<int, 4>{}); mma(f1); weave();
+            load_frag(f1, ab, gb, std::integral_constant<int, 5>{}); mma(f0); weave();
+            load_frag(f0, ab, gb, std::integral_constant<int, 6>{}); mma(f1); weave();
+            load_frag(f1, ab, gb, std::integral_constant<int, 7>{}); mma(f0); weave();
+            mma(f1);
+            if (single_buf && t + 1 < t_end) {
+                __syncthreads();                                 // everybody is done reading the buffer
+                issue_dma(t + 1, 0);
             }
         }
-        if (single_buf && t + 1 < t_end) {
-            __syncthreads();                                 // everybody is done reading the buffer
-            issue_dma(t + 1, 0);
-        }
-    }
+    };
+    if (do_bias) run(std::true_type{}); else run(std::false_type{});
     // slab[split][co][tap][ci]  (dW layout [Cout][kh][kw][Cin], rows = ldy channels)
     const int ktot = g.ldw;
     float* out = slab_w + (long long)split * g.N * ktot;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int col = wave * g.C + ci0 + c * 16 + (lane & 15);
+        for (int t9 = 0; t9 < 9; ++t9) {
+            const int col = t9 * g.C + ci0 + ct * 16 + (lane & 15);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int co = co0 + a * 16 + (lane >> 4) * 4 + j;
-                if (co < g.N) out[(long long)co * ktot + col] = acc[a][c][j];
+                const int co = co0 + (2 * ap + a) * 16 + (lane >> 4) * 4 + j;
+                if (co < g.N) out[(long long)co * ktot + col] = acc[a][t9][j];
             }
         }
     if (do_bias && (lane & 15) == 0) {
         float* ob = slab_b + (long long)split * g.N;
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int co = co0 + a * 16 + (lane >> 4) * 4 + j;
+                const int co = co0 + (2 * ap + a) * 16 + (lane >> 4) * 4 + j;
                 if (co < g.N) ob[co] = accb[a][j];
             }
     }
@@ -1640,6 +1748,23 @@ __global__ void k_head_grad_pack(const bf16_raw* __restrict__ dloc, const bf16_r
     out[i] = v;
 }
 
+// Development knobs: read from the environment on first use, overridable at run time through ssd_dev_knob (A/B timing
+// of kernel variants inside one process).  Production code never sets them.
+struct Knob { const char* name; int value; bool init; };
+Knob g_knobs[] = {{"SSD_ABLATE", 0, false}, {"SSD_DGRAD_S2", 0, false}, {"SSD_CONV_VARIANT", 0, false}, {"SSD_CONV_PATCH", 0, false},
+                  {"SSD_CONV_TILE", 0, false}, {"SSD_SPLITK", 0, false}, {"SSD_WGRAD_DMA", 0, false}, {"SSD_WGRAD_PATCH", 0, false},
+                  {"SSD_WGRAD_PATCH_SINGLE", 0, false}, {"SSD_EPI_STAGED", 0, false}};
+Knob* find_knob(const char* name) {
+    for (Knob& k : g_knobs) if (!strcmp(k.name, name)) return &k;
+    return nullptr;
+}
+int knob(const char* name, int dflt) {
+    Knob* k = find_knob(name);
+    if (!k) return dflt;
+    if (!k->init) { const char* e = getenv(name); k->value = e ? atoi(e) : dflt; k->init = true; }
+    return k->value;
+}
+
 ConvGeom make_geom(int B, int H, int W, int C, int Ho, int Wo, int N, int KH, int KW, int mul, int div, int pad_t,
                    int pad_l) {
     ConvGeom g;
@@ -1651,12 +1776,9 @@ ConvGeom make_geom(int B, int H, int W, int C, int Ho, int Wo, int N, int KH, in
     g.cpt = C / 8;
     g.d_hw = make_fastdiv(Ho * Wo);
     g.d_w = make_fastdiv(Wo);
-    static int abl = -1;
-    if (abl < 0) { const char* e = getenv("SSD_ABLATE"); abl = e ? atoi(e) : 0; }
-    g.ablate = abl;
+    g.ablate = knob("SSD_ABLATE", 0);
     g.s2 = 0;
-    static int s2on = -1;
-    if (s2on < 0) { const char* e = getenv("SSD_DGRAD_S2"); s2on = e ? atoi(e) : 1; }
+    const int s2on = knob("SSD_DGRAD_S2", 1);
     if (div == 2 && s2on && g.cpt % 8 == 0) {
         g.s2 = 1;
         for (int p = 0; p < 2; ++p) { g.cls_h[p] = (Ho + 1 - p) / 2; g.cls_w[p] = (Wo + 1 - p) / 2; }
@@ -1666,12 +1788,7 @@ ConvGeom make_geom(int B, int H, int W, int C, int Ho, int Wo, int N, int KH, in
 }
 
 int igemm_variant() {                       // SSD_CONV_VARIANT=0: register-staged kernel, 1: LDS-DMA kernels, 2 (default): + 8-phase 256x256
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("SSD_CONV_VARIANT");
-        v = e ? atoi(e) : 2;
-    }
-    return v;
+    return knob("SSD_CONV_VARIANT", 2);
 }
 
 template <int EPI>
@@ -1683,8 +1800,7 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
     ep.slab = nullptr;
     ep.ksplit = 1;
     const unsigned gm = (unsigned)((g.M + 127) / 128);
-    static int use_patch = -1;
-    if (use_patch < 0) { const char* e = getenv("SSD_CONV_PATCH"); use_patch = e ? atoi(e) : 128; }   // max N served
+    const int use_patch = knob("SSD_CONV_PATCH", 128);   // max N served
     if (igemm_variant() >= 1 && g.KH == 3 && g.KW == 3 && g.mul == 1 && g.div == 1 && g.pad_t == 1 && g.pad_l == 1 &&
         g.C % 64 == 0 && g.H == g.Ho && g.W == g.Wo && g.N <= use_patch && g.H >= 16 && g.W >= 16) {
         const int tiles_x = (g.Wo + 15) / 16, tiles_y = (g.Ho + 15) / 16;
@@ -1707,8 +1823,7 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
     if (igemm_variant() >= 1) {
         // tile choice: the CU ingests ~28 B/clk from L2, so MACs per staged byte decide the ceiling: prefer the
         // largest tile that still gives every CU work (>= ~2 workgroups per CU), SSD_CONV_TILE overrides (testing)
-        static int force = -1;
-        if (force < 0) { const char* e = getenv("SSD_CONV_TILE"); force = e ? atoi(e) : 0; }
+        const int force = knob("SSD_CONV_TILE", 0);
         const long long wg_128 = (long long)((g.M + 127) / 128);
         const long long wg_256 = (long long)((g.M + 255) / 256);
         int bm = 128, bn = g.N <= 64 ? 64 : 128;
@@ -1721,8 +1836,7 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
         // split-K for skinny problems (few tiles, long k loop): partial sums to the caller's workspace
         unsigned ksplit = 1;
         {
-            static int sk_on = -1;
-            if (sk_on < 0) { const char* e = getenv("SSD_SPLITK"); sk_on = e ? atoi(e) : 1; }
+            const int sk_on = knob("SSD_SPLITK", 1);
             const long long tiles = (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn);
             const int nks_all = g.s2 ? 0 : (g.nchunks + 7) / 8;
             if (sk_on && ws && tiles < 160 && nks_all >= 8) {
@@ -1818,6 +1932,15 @@ bool geom_ok(int B, int H, int W, int C, int Ho, int Wo, int N, int K) {
 
 extern "C" {
 
+int ssd_dev_knob(const char* name, int value) {
+    if (!name) return SSD_ERR_VALUE;
+    Knob* k = find_knob(name);
+    if (!k) return SSD_ERR_VALUE;
+    k->value = value;
+    k->init = true;
+    return SSD_OK;
+}
+
 int ssd_conv2d_fwd(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
                    int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int relu, void* ws, size_t ws_bytes,
                    void* stream) {
@@ -1855,15 +1978,11 @@ int ssd_conv2d_bwd_data(const void* dy, const void* w_t, const void* relu_src, v
 }
 
 static int wgrad_dma() {                    // SSD_WGRAD_DMA=1: LDS-DMA weight-gradient kernel (default: register-staged)
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("SSD_WGRAD_DMA"); v = e ? atoi(e) : 0; }
-    return v;
+    return knob("SSD_WGRAD_DMA", 0);
 }
 
 static int wgrad_patch_min_hw() {           // SSD_WGRAD_PATCH = smallest feature-map side served by the patch kernel (0: off)
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("SSD_WGRAD_PATCH"); v = e ? atoi(e) : 32; }
-    return v;
+    return knob("SSD_WGRAD_PATCH", 32);
 }
 
 static bool wgrad_use_patch(int H, int W, int Ho, int Wo, int Cin, int ksize, int stride, int pad_t, int pad_l) {
@@ -1876,8 +1995,7 @@ static void wgrad_patch_plan(int B, int Ho, int Wo, int Cin, int Cout, int* tile
     *tiles_x = (Wo + 15) / 16; *tiles_y = (Ho + 15) / 16;
     const int ntiles = B * *tiles_x * *tiles_y;
     const int groups = (Cin / 64) * ((Cout + 63) / 64);
-    static int wp_mult = -1;
-    if (wp_mult < 0) { const char* e = getenv("SSD_WGRAD_PATCH_SINGLE"); wp_mult = (e && atoi(e)) ? 2 : 1; }
+    const int wp_mult = knob("SSD_WGRAD_PATCH_SINGLE", 0) ? 2 : 1;
     int want = 256 * wp_mult / groups;                       // one (two when single-buffered) workgroup per CU
     if (want < 1) want = 1;
     if (want > ntiles) want = ntiles;
@@ -1931,8 +2049,7 @@ int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias
         float* slab_w = static_cast<float*>(ws);
         float* slab_b = slab_w + (size_t)ns * ldy * ktot;
         hipStream_t s = (hipStream_t)stream;
-        static int single = -1;
-        if (single < 0) { const char* e = getenv("SSD_WGRAD_PATCH_SINGLE"); single = e ? atoi(e) : 0; }
+        const int single = knob("SSD_WGRAD_PATCH_SINGLE", 0);
         const size_t lds = (single ? 1 : 2) * WP_BUF;
         static bool set = false;
         if (!set) {
@@ -1941,7 +2058,7 @@ int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias
             set = true;
         }
         const unsigned grid = (unsigned)((Cin / 64) * ((Cout + 63) / 64) * ns);
-        hipLaunchKernelGGL(k_conv3x3_wgrad_patch, dim3(grid), dim3(576), lds, s, static_cast<const bf16_raw*>(x),
+        hipLaunchKernelGGL(k_conv3x3_wgrad_patch, dim3(grid), dim3(512), lds, s, static_cast<const bf16_raw*>(x),
                            static_cast<const bf16_raw*>(dy), slab_w, dbias ? slab_b : nullptr, g, tx, ty, tps, ns, Cout, single);
         if (hipGetLastError() != hipSuccess) return SSD_ERR_LAUNCH;
         const long long nw = (long long)Cout * ktot;            // multiple of 4 (ktot = 9*Cin, Cin % 8 == 0)

@@ -1381,8 +1381,24 @@ __global__ __launch_bounds__((BMO / (16 * AT)) * (BNC / 64) * 64) void k_conv_wg
 // tiles (4 co-tiles x 9 taps x 4 ci-tiles) are dealt to eight waves, 18 each (2 co-tiles x 9 taps x 1 ci-tile), so
 // that all four SIMDs carry the same MFMA load (one wave per tap left one SIMD with 3 waves and the others with 2).
 // ~128 MACs per byte brought into the CU, versus 32 for the generic 128x128 tile that re-stages X for every tap.
-constexpr int WP_DY_BYTES = 256 * 128;                     // 32 KiB
-constexpr int WP_BUF = WP_DY_BYTES + PATCH_BYTES;          // one buffer: dY tile + X patch
+// Block geometry (template): BH output rows x 8*BW8 output columns.  The block's pixels are consumed as "pair groups"
+// of 16 (two rows x eight columns); a k-step (32 pixels) takes two of them; an odd count is padded with an all-zero
+// dY group.  Three shapes cover the SSD300 maps: 16x16 (300, 150, 75), 6x40 (38) and 10x24 (19).
+template <int BH, int BW8>
+struct WpGeom {
+    static constexpr int BW = BW8 * 8;
+    static constexpr int PW = BW + 2, PH = BH + 2;             // halo patch
+    static constexpr int PPIX = PW * PH;
+    static constexpr int P_INSTR = (PPIX * 8 + 63) / 64;       // one-KiB DMA instructions (8 pixels each)
+    static constexpr int P_BYTES = P_INSTR * 1024;
+    static constexpr int NPG = (BH / 2) * BW8;                 // pair groups
+    static constexpr int KS = (NPG + 1) / 2;                   // k-steps per block
+    static constexpr int DY_PIX = KS * 32;
+    static constexpr int DY_BYTES = DY_PIX * 128;
+    static constexpr int DY_INSTR = DY_PIX / 8;
+    static constexpr int BUF = DY_BYTES + P_BYTES;             // one buffer: dY tile + X patch
+    static_assert(BH % 2 == 0 && DY_INSTR % 8 == 0, "block shape");
+};
 
 // 32-byte column group permutation of a 128-byte pixel row.  A half-wave of a transposing read touches 8 CONSECUTIVE
 // pixel rows (any alignment: taps shift them); (p & 1, (p >> 1) & 3) then takes all eight values, i.e. the eight
@@ -1390,14 +1406,14 @@ constexpr int WP_BUF = WP_DY_BYTES + PATCH_BYTES;          // one buffer: dY til
 // keep eight per-lane base addresses and reach every (k-step, tap, half) with an immediate offset.
 __device__ __forceinline__ int wp_key(int px) { return (px >> 1) & 3; }
 
+template <int BH, int BW8>
 __global__ __launch_bounds__(512) void k_conv3x3_wgrad_patch(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ dy,
                                                              float* __restrict__ slab_w, float* __restrict__ slab_b,
                                                              ConvGeom g, int tiles_x, int tiles_y, int tiles_per_split,
                                                              int nsplit, int cout, int single_buf) {
     // g: source = x (B,H,W,C), destination = dy (Ho=H, Wo=W, N = ldy)
+    using G = WpGeom<BH, BW8>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    auto s_dy = [&](int buf) { return smem + buf * WP_BUF; };
-    auto s_px = [&](int buf) { return smem + buf * WP_BUF + WP_DY_BYTES; };
 
     const int tid = threadIdx.x, lane = tid & 63;
     // eight waves (two per SIMD, equal work): wave w owns output-channel tiles {2(w&1), 2(w&1)+1} x input-channel
@@ -1413,39 +1429,40 @@ __global__ __launch_bounds__(512) void k_conv3x3_wgrad_patch(const bf16_raw* __r
     const int ntiles = g.B * tiles_x * tiles_y;
     const int t_begin = split * tiles_per_split, t_end = min(ntiles, t_begin + tiles_per_split);
 
-    // DMA ownership: dY tile = 32 instructions, patch = 41; instruction i of each goes to wave i % 8
+    // DMA ownership: instruction i of the dY tile / of the patch goes to wave i % 8
     auto issue_dma = [&](int t, int buf) {
         int r = t;
         const int tx = r % tiles_x; r /= tiles_x;
         const int ty = r % tiles_y;
         const int b = r / tiles_y;
-        const int y0 = ty * 16, x0 = tx * 16;
+        const int y0 = ty * BH, x0 = tx * G::BW;
+        char* base = smem + buf * G::BUF;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = wave + 8 * j;
-            {                                               // 8 pixels x 128 B per instruction
-                const int px = 8 * i + (lane >> 3), sl = lane & 7;
-                const int c16 = (((sl >> 1) ^ wp_key(px)) << 1) | (sl & 1);
-                const int y = y0 + (px >> 4), xx = x0 + (px & 15);
-                const int co = co0 + c16 * 8;
-                const bool ok = y < g.Ho && xx < g.Wo && co < g.N;
-                const bf16_raw* src = ok ? dy + ((unsigned)((b * g.Ho + y) * g.Wo + xx) * (unsigned)g.N + (unsigned)co)
-                                         : reinterpret_cast<const bf16_raw*>(g_zero16);
-                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(s_dy(buf) + i * 1024), 16, 0, 0);
-            }
+        for (int j = 0; j < G::DY_INSTR / 8; ++j) {
+            const int i = wave + 8 * j;                     // 8 pixel slots x 128 B per instruction
+            const int kk = 8 * i + (lane >> 3), sl = lane & 7;
+            const int c16 = (((sl >> 1) ^ wp_key(kk)) << 1) | (sl & 1);
+            const int pg = kk >> 4;                         // pair group -> (row pair, column group)
+            const int rp = pg / BW8, xg = pg - rp * BW8;
+            const int y = y0 + 2 * rp + ((kk >> 3) & 1), xx = x0 + xg * 8 + (kk & 7);
+            const int co = co0 + c16 * 8;
+            const bool ok = pg < G::NPG && y < g.Ho && xx < g.Wo && co < g.N;
+            const bf16_raw* src = ok ? dy + ((unsigned)((b * g.Ho + y) * g.Wo + xx) * (unsigned)g.N + (unsigned)co)
+                                     : reinterpret_cast<const bf16_raw*>(g_zero16);
+            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(base + i * 1024), 16, 0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
+        for (int j = 0; j < (G::P_INSTR + 7) / 8; ++j) {
             const int i = wave + 8 * j;
-            if (i < PATCH_INSTR) {
+            if (i < G::P_INSTR) {
                 const int pp = 8 * i + (lane >> 3), sl = lane & 7;
                 const int c16 = (((sl >> 1) ^ wp_key(pp)) << 1) | (sl & 1);
-                const int py = pp / PATCH_W, px = pp - py * PATCH_W;
+                const int py = pp / G::PW, px = pp - py * G::PW;
                 const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-                const bool ok = pp < PATCH_PIX && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+                const bool ok = pp < G::PPIX && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
                 const bf16_raw* src = ok ? x + ((unsigned)((b * g.H + iy) * g.W + ix) * (unsigned)g.C + (unsigned)(ci0 + c16 * 8))
                                          : reinterpret_cast<const bf16_raw*>(g_zero16);
-                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(s_px(buf) + i * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(base + G::DY_BYTES + i * 1024), 16, 0, 0);
             }
         }
     };
@@ -1463,25 +1480,25 @@ __global__ __launch_bounds__(512) void k_conv3x3_wgrad_patch(const bf16_raw* __r
 #pragma unroll
     for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
 
-    // single_buf: one LDS buffer (74 KB) so that TWO workgroups share a CU and hide each other's DMA latency;
-    // otherwise two buffers in one workgroup (150 KB), next block's DMA in flight during this block's MFMAs
+    // single_buf: one LDS buffer so that TWO workgroups share a CU and hide each other's DMA latency;
+    // otherwise two buffers in one workgroup, next block's DMA in flight during this block's MFMAs
     if (t_begin < t_end) issue_dma(t_begin, 0);
-    // MFMA k index <-> block pixel: k-step ks covers block rows 2ks, 2ks+1; within it lane group gq and `half` select
-    //   row 2ks + (gq>>1), column 8*half + 4*(gq&1) + (li>>2)
-    // so that the 8 rows of a half-wave instruction are consecutive pixels.  All address arithmetic is hoisted: the dY
-    // row of a lane is base + immediate, and a patch row is one of eight per-lane bases (pixel offset mod 8) + immediate.
+    // MFMA k index <-> block pixel: k-step ks, `half` select pair group pg = 2ks + half = (row pair rp, column group xg);
+    // within it lane group gq and the lane select row 2rp + (gq>>1), column 8xg + 4*(gq&1) + (li>>2), so that the 8 rows
+    // of a half-wave instruction are consecutive pixels.  All address arithmetic is hoisted: the dY row of a lane is
+    // base + immediate, and a patch row is one of eight per-lane bases (pixel offset mod 8) + immediate.
     const int gq = lane >> 4, li = lane & 15;
     int abase[2];
     {
-        const int kk0 = (gq >> 1) * 16 + (gq & 1) * 4 + (li >> 2);
+        const int kk0 = (gq >> 1) * 8 + (gq & 1) * 4 + (li >> 2);
 #pragma unroll
         for (int a = 0; a < 2; ++a) abase[a] = kk0 * 128 + (((2 * ap + a) ^ wp_key(kk0)) << 5) + (li & 3) * 8;
     }
     int gbase[8];
     {
-        const int p0 = (gq >> 1) * PATCH_W + (gq & 1) * 4 + (li >> 2);
+        const int p0 = (gq >> 1) * G::PW + (gq & 1) * 4 + (li >> 2);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) gbase[r] = WP_DY_BYTES + (p0 + r) * 128 + ((ct ^ wp_key(p0 + r)) << 5) + (li & 3) * 8;
+        for (int r = 0; r < 8; ++r) gbase[r] = G::DY_BYTES + (p0 + r) * 128 + ((ct ^ wp_key(p0 + r)) << 5) + (li & 3) * 8;
     }
     typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
     // fragments of one k-step: 4 dY reads + 18 patch reads (all with immediate offsets)
@@ -1493,18 +1510,19 @@ __global__ __launch_bounds__(512) void k_conv3x3_wgrad_patch(const bf16_raw* __r
 #pragma unroll
             for (int a = 0; a < 2; ++a)
                 reinterpret_cast<s16x4_t*>(&f.fa[a])[half] =
-                    __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + ab[a] + ks * 4096 + half * 1024));
+                    __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + ab[a] + (ks * 2 + half) * 2048));
 #pragma unroll
         for (int t9 = 0; t9 < 9; ++t9)
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                constexpr int dummy = 0; (void)dummy;
-                const int ctap = ks * 2 * PATCH_W + half * 8 + (t9 / 3) * PATCH_W + (t9 % 3);       // compile-time pixel offset
+                const int pg = (ks * 2 + half) < G::NPG ? (ks * 2 + half) : 0;   // padding group: any finite data (dY is zero there)
+                const int rp = pg / BW8, xg = pg - rp * BW8;
+                const int ctap = (2 * rp + t9 / 3) * G::PW + xg * 8 + (t9 % 3);   // compile-time pixel offset
                 reinterpret_cast<s16x4_t*>(&f.fb[t9])[half] =
                     __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + gb[ctap & 7] + (ctap >> 3) * 1024));
             }
     };
-    // the block loop exists twice (with / without the bias MFMAs) so that its body has no branch: the eight k-steps of
+    // the block loop exists twice (with / without the bias MFMAs) so that its body has no branch: the k-steps of
     // a block are one basic block, software-pipelined by hand (fragments of k-step ks+1 are read during the MFMAs of ks)
     auto run = [&](auto bias_tag) {
         constexpr bool BIAS = decltype(bias_tag)::value;
@@ -1513,7 +1531,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wgrad_patch(const bf16_raw* __r
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (!single_buf && t + 1 < t_end) issue_dma(t + 1, cur ^ 1);
-            const int boff = cur * WP_BUF;
+            const int boff = cur * G::BUF;
             int ab[2], gb[8];
 #pragma unroll
             for (int a = 0; a < 2; ++a) ab[a] = abase[a] + boff;
@@ -1545,6 +1563,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wgrad_patch(const bf16_raw* __r
                 }
                 if constexpr (BIAS) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             };
+            static_assert(G::KS == 8, "the hand-unrolled pipeline below assumes eight k-steps per block");
             load_frag(f0, ab, gb, std::integral_constant<int, 0>{});
             load_frag(f1, ab, gb, std::integral_constant<int, 1>{}); mma(f0); weave();
             load_frag(f0, ab, gb, std::integral_constant<int, 2>{}); mma(f1); weave();
@@ -1753,7 +1772,7 @@ __global__ void k_head_grad_pack(const bf16_raw* __restrict__ dloc, const bf16_r
 struct Knob { const char* name; int value; bool init; };
 Knob g_knobs[] = {{"SSD_ABLATE", 0, false}, {"SSD_DGRAD_S2", 0, false}, {"SSD_CONV_VARIANT", 0, false}, {"SSD_CONV_PATCH", 0, false},
                   {"SSD_CONV_TILE", 0, false}, {"SSD_SPLITK", 0, false}, {"SSD_WGRAD_DMA", 0, false}, {"SSD_WGRAD_PATCH", 0, false},
-                  {"SSD_WGRAD_PATCH_SINGLE", 0, false}, {"SSD_EPI_STAGED", 0, false}};
+                  {"SSD_WGRAD_PATCH_SINGLE", 0, false}, {"SSD_WGRAD_PATCH_SHAPE", 0, false}};
 Knob* find_knob(const char* name) {
     for (Knob& k : g_knobs) if (!strcmp(k.name, name)) return &k;
     return nullptr;
@@ -1982,7 +2001,7 @@ static int wgrad_dma() {                    // SSD_WGRAD_DMA=1: LDS-DMA weight-g
 }
 
 static int wgrad_patch_min_hw() {           // SSD_WGRAD_PATCH = smallest feature-map side served by the patch kernel (0: off)
-    return knob("SSD_WGRAD_PATCH", 32);
+    return knob("SSD_WGRAD_PATCH", 16);
 }
 
 static bool wgrad_use_patch(int H, int W, int Ho, int Wo, int Cin, int ksize, int stride, int pad_t, int pad_l) {
@@ -1991,8 +2010,26 @@ static bool wgrad_use_patch(int H, int W, int Ho, int Wo, int Cin, int ksize, in
            H >= mn && W >= mn;
 }
 
+// block shape of the patch kernel for a map: the candidate with the least padded work (0: 16x16, 1: 6x40, 2: 10x24)
+static int wgrad_patch_shape(int Ho, int Wo, int* bh, int* bw) {
+    static const int shapes[3][3] = {{16, 16, 16}, {6, 40, 15}, {10, 24, 15}};   // rows, columns, pair groups (of 16 slots)
+    int best = 0;
+    double best_cost = 0;
+    for (int i = 0; i < 3; ++i) {
+        // every block costs eight k-steps whatever its shape: fewest blocks wins
+        const double cost = (double)((Ho + shapes[i][0] - 1) / shapes[i][0]) * ((Wo + shapes[i][1] - 1) / shapes[i][1]);
+        if (i == 0 || cost < best_cost) { best = i; best_cost = cost; }
+    }
+    const int forced = knob("SSD_WGRAD_PATCH_SHAPE", -1);
+    if (forced >= 0 && forced < 3) best = forced;
+    *bh = shapes[best][0]; *bw = shapes[best][1];
+    return best;
+}
+
 static void wgrad_patch_plan(int B, int Ho, int Wo, int Cin, int Cout, int* tiles_x, int* tiles_y, int* tps, int* ns) {
-    *tiles_x = (Wo + 15) / 16; *tiles_y = (Ho + 15) / 16;
+    int bh, bw;
+    wgrad_patch_shape(Ho, Wo, &bh, &bw);
+    *tiles_x = (Wo + bw - 1) / bw; *tiles_y = (Ho + bh - 1) / bh;
     const int ntiles = B * *tiles_x * *tiles_y;
     const int groups = (Cin / 64) * ((Cout + 63) / 64);
     const int wp_mult = knob("SSD_WGRAD_PATCH_SINGLE", 0) ? 2 : 1;
@@ -2050,16 +2087,27 @@ int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias
         float* slab_b = slab_w + (size_t)ns * ldy * ktot;
         hipStream_t s = (hipStream_t)stream;
         const int single = knob("SSD_WGRAD_PATCH_SINGLE", 0);
-        const size_t lds = (single ? 1 : 2) * WP_BUF;
-        static bool set = false;
-        if (!set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_wgrad_patch), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    2 * WP_BUF) != hipSuccess) return SSD_ERR_LAUNCH;
-            set = true;
-        }
         const unsigned grid = (unsigned)((Cin / 64) * ((Cout + 63) / 64) * ns);
-        hipLaunchKernelGGL(k_conv3x3_wgrad_patch, dim3(grid), dim3(512), lds, s, static_cast<const bf16_raw*>(x),
-                           static_cast<const bf16_raw*>(dy), slab_w, dbias ? slab_b : nullptr, g, tx, ty, tps, ns, Cout, single);
+        int bh, bw;
+        const int shape = wgrad_patch_shape(Ho, Wo, &bh, &bw);
+#define SSD_LAUNCH_WP(BH_, BW8_)                                                                                    \
+        do {                                                                                                        \
+            using G_ = WpGeom<BH_, BW8_>;                                                                           \
+            auto kern_ = k_conv3x3_wgrad_patch<BH_, BW8_>;                                                          \
+            static bool set_ = false;                                                                               \
+            if (!set_) {                                                                                            \
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        2 * G_::BUF) != hipSuccess) return SSD_ERR_LAUNCH;                           \
+                set_ = true;                                                                                        \
+            }                                                                                                       \
+            hipLaunchKernelGGL(kern_, dim3(grid), dim3(512), (size_t)(single ? 1 : 2) * G_::BUF, s,                  \
+                               static_cast<const bf16_raw*>(x), static_cast<const bf16_raw*>(dy), slab_w,          \
+                               dbias ? slab_b : nullptr, g, tx, ty, tps, ns, Cout, single);                         \
+        } while (0)
+        if (shape == 1) SSD_LAUNCH_WP(6, 5);
+        else if (shape == 2) SSD_LAUNCH_WP(10, 3);
+        else SSD_LAUNCH_WP(16, 2);
+#undef SSD_LAUNCH_WP
         if (hipGetLastError() != hipSuccess) return SSD_ERR_LAUNCH;
         const long long nw = (long long)Cout * ktot;            // multiple of 4 (ktot = 9*Cin, Cin % 8 == 0)
         const unsigned nbw = (unsigned)((nw / 4 + 255) / 256), nbb = dbias ? (unsigned)((Cout + 255) / 256) : 0u;

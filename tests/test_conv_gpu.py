@@ -45,6 +45,8 @@ CASES = [
     (1, 70, 70, 256, 320, 3, 1, "same"),     # 256-wide tiles of the LDS-DMA implicit GEMM (M = 4900, N = 320)
     (2, 38, 38, 64, 128, 3, 2, "same"),      # stride-2 data gradient by parity classes (even size, pad (0,1))
     (3, 19, 19, 128, 64, 3, 2, "same"),      # stride-2 data gradient by parity classes (odd size, pad (1,1))
+    (2, 19, 19, 128, 192, 3, 1, "same"),     # weight gradient with 10x24 blocks (the 19x19 maps)
+    (1, 25, 20, 64, 64, 3, 1, "same"),       # 10x24 blocks, partial in both dims
 ]
 
 
@@ -103,6 +105,27 @@ def test_conv_fwd_bwd(ops, case):
     # deterministic
     dw2, _ = ops.conv2d_bwd_weight(xd, dyd, Cout, k, stride, pt, pl)
     assert torch.equal(dw, dw2)
+
+
+@pytest.mark.parametrize("shape", [0, 1, 2])
+def test_wgrad_patch_block_shapes(ops, shape):
+    """Every block shape of the LDS-patch weight-gradient kernel (16x16, 6x40, 10x24) gives the same gradient;
+    the shape is a tuning choice only (forced here through the development knob)."""
+    from ssd_object_detection_amd import _lib
+    B, H, W, Cin, Cout = 2, 23, 45, 64, 80
+    g = torch.Generator().manual_seed(11 + shape)
+    x = torch.randn((B, H, W, Cin), generator=g).bfloat16()
+    dy = torch.randn((B, H, W, Cout), generator=g).bfloat16()
+    w = torch.zeros((Cout, 3, 3, Cin), requires_grad=True)
+    ref_conv(x.float(), w, None, 3, 1, 1, 1, H, W, False).backward(dy.float())
+    L = _lib.lib()
+    assert L.ssd_dev_knob(b"SSD_WGRAD_PATCH_SHAPE", shape) == 0
+    try:
+        dw, db = ops.conv2d_bwd_weight(x.cuda(), dy.cuda(), Cout, 3, 1, 1, 1)
+    finally:
+        L.ssd_dev_knob(b"SSD_WGRAD_PATCH_SHAPE", -1)
+    assert (dw.cpu() - w.grad).abs().max().item() <= 1e-3 * max(1.0, w.grad.abs().max().item())
+    assert (db.cpu() - dy.float().sum((0, 1, 2))).abs().max().item() <= 1e-3 * 60
 
 
 def test_wgrad_padded_dy(ops):

@@ -23,6 +23,10 @@ elif mode == "head":
     A = H * H * per_cell
     loc = torch.empty((B, A, 4), device="cuda", dtype=torch.bfloat16); conf = torch.empty((B, A, 81), device="cuda", dtype=torch.bfloat16)
     run = lambda: ops.conv2d_head_fwd(x, w, b, loc, conf, per_cell, 81, 0)
+elif mode == "wgrad":
+    dy = torch.randn((B, H, H, Cout), device="cuda").bfloat16()
+    dw, db = ops.conv2d_bwd_weight(x, dy, Cout, k, 1, pt, pt)
+    run = lambda: ops.conv2d_bwd_weight(x, dy, Cout, k, 1, pt, pt, dw=dw, dbias=db)
 else:
     # data gradient of a Cin->Cout conv: dy [B,H,H,Cout], w_t [Cin][k][k][Cout]
     dy = torch.randn((B, H, H, Cout), device="cuda").bfloat16()

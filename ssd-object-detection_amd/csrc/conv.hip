@@ -1372,6 +1372,195 @@ __global__ __launch_bounds__((BMO / (16 * AT)) * (BNC / 64) * 64) void k_conv_wg
 }
 
 // ------------------------------------------------------------------------------------------------
+// Weight gradient as a plain GEMM over pixels, 256 output channels x 256 (tap, ci) columns per workgroup, 64 pixels
+// per step (the 1x1 and the strided layers with >= 256 channels; the 3x3 / stride-1 layers use the patch kernel below).
+//   dW[co][col] += sum_m dY[m][co] * Xcol[m][col]
+// Both tiles are [pixel][256 channels] images (512-byte rows) filled by buffer LDS-DMA (a lane whose pixel / column is
+// padding gets an out-of-range offset = zeros) and read with transposing LDS reads.  The 32-byte column groups of a
+// row are XORed with (row & 7): the eight consecutive rows of a half-wave read then hit eight bank groups, and since
+// the key has period 8 every read address is a per-lane base + immediate.  Eight waves (2 x 4), each 128 co x 64 cols
+// = 32 accumulator tiles, 64 MFMAs per step; two LDS buffers (128 KB), one barrier per step.
+constexpr int WT_TILE = 64 * 512;                          // one [64 px][256 ch] image
+__global__ __launch_bounds__(512) void k_conv_wgrad_tile(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ dy,
+                                                         float* __restrict__ slab_w, float* __restrict__ slab_b, ConvGeom g,
+                                                         int m_per_split, int nsplit, int cout) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave & 1, wave_n = wave >> 1;           // 128 channels x 64 columns per wave
+    // XCD-aware order when the splits are a multiple of 8: all tiles of one pixel split run consecutively on ONE XCD
+    // (workgroup L -> XCD L % 8) and share its rows through that L2; otherwise plain order, which keeps every XCD busy
+    const int ktot = g.ldw;
+    const int ctiles = (ktot + 255) >> 8, mtiles = (cout + 255) >> 8, tiles = ctiles * mtiles;
+    int split, tile;
+    if ((nsplit & 7) == 0) {
+        const int kx = blockIdx.x >> 3;
+        split = (kx / tiles) * 8 + (blockIdx.x & 7);
+        tile = kx % tiles;
+    } else {
+        split = blockIdx.x / tiles;
+        tile = blockIdx.x - split * tiles;
+    }
+    if (split >= nsplit) return;
+    const int bx = tile % ctiles, by = tile / ctiles;
+    const int col0 = bx * 256, co0 = by * 256;
+    const int m_begin = split * m_per_split;
+    const int m_end = min(g.M, m_begin + m_per_split);
+
+    // DMA: instruction i (= wave + 8j, j < 4) fills tile rows 2i, 2i+1; lane L -> row 2i + (L>>5), physical chunk L & 31
+    const __amdgpu_buffer_rsrc_t dyres = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (unsigned)g.M * (unsigned)g.N * 2u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (unsigned)g.B * g.H * g.W * g.C * 2u, 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;
+    const int drow = lane >> 5;
+    int rowj[4];
+    unsigned dycol[4], xcol[4];                                // byte offset of the lane's chunk inside a pixel row, OOB if padding
+    int xkh[4], xkw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 2 * (wave + 8 * j) + drow;
+        rowj[j] = row;
+        const int pc = lane & 31;                              // physical 16-byte chunk
+        const int lg = ((pc >> 1) & 8) | (((pc >> 1) ^ row) & 7);   // logical 32-byte group
+        const int ch = (lg * 2 + (pc & 1)) * 8;                // channel / column of the tile
+        dycol[j] = co0 + ch < g.N ? (unsigned)(co0 + ch) * 2u : OOB;
+        const int q = (col0 + ch) >> 3;
+        if (q < g.nchunks) {
+            const int tap = q / g.cpt;
+            xcol[j] = (unsigned)(q - tap * g.cpt) * 16u;
+            xkh[j] = tap / g.KW;
+            xkw[j] = tap - xkh[j] * g.KW;
+        } else {
+            xcol[j] = OOB; xkh[j] = 0; xkw[j] = 0;
+        }
+    }
+    const bool pointwise = g.KH == 1 && g.KW == 1 && g.mul == 1 && g.pad_t == 0 && g.pad_l == 0;   // source pixel = output pixel
+    auto issue_dma = [&](int mstep, int buf) {
+        char* base = smem + buf * (2 * WT_TILE);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = mstep + rowj[j];
+            const bool mok = m < m_end;
+            const unsigned od = (unsigned)m * (unsigned)g.N * 2u + dycol[j];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dyres, (lds_void*)(base + (wave + 8 * j) * 1024), 16,
+                                                     (mok && dycol[j] != OOB) ? od : OOB, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = mstep + rowj[j];
+            bool ok = m < m_end && xcol[j] != OOB;
+            unsigned pix;
+            if (pointwise) {
+                pix = (unsigned)m;
+            } else {
+                const int mm = ok ? m : 0;
+                const int b = fdiv(mm, g.d_hw);
+                const int rem = mm - b * g.d_hw.d;
+                const int oy = fdiv(rem, g.d_w);
+                const int ox = rem - oy * g.d_w.d;
+                const int iy = oy * g.mul - g.pad_t + xkh[j], ix = ox * g.mul - g.pad_l + xkw[j];
+                ok = ok && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+                pix = (unsigned)((b * g.H + iy) * g.W + ix);
+            }
+            const unsigned ox_ = pix * (unsigned)g.C * 2u + xcol[j];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)(base + WT_TILE + (wave + 8 * j) * 1024), 16,
+                                                     ok ? ox_ : OOB, 0, 0, 0);
+        }
+    };
+
+    f32x4_t acc[8][4];
+    f32x4_t accb[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        accb[a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool do_bias = slab_b != nullptr && bx == 0 && wave_n == 0;
+    bf16x8_t ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+
+    // MFMA k index <-> tile row: sub-step ksub, lane group gq, `half`: row = 32 ksub + 16 (gq>>1) + 8 half + 4 (gq&1) + (li>>2)
+    const int gq = lane >> 4, li = lane & 15;
+    const int kk0 = (gq >> 1) * 16 + (gq & 1) * 4 + (li >> 2);
+    const int key = kk0 & 7;
+    int abase[8], bbase[4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) abase[a] = kk0 * 512 + ((wave_m * 8 + (a ^ key)) << 5) + (li & 3) * 8;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int gl = wave_n * 4 + c;
+        bbase[c] = WT_TILE + kk0 * 512 + (((gl & 8) | ((gl & 7) ^ key)) << 5) + (li & 3) * 8;
+    }
+    typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
+    auto rd = [&](int addr) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + addr)); };
+
+    const int nsteps = (m_end - m_begin + 63) / 64;
+    if (nsteps > 0) issue_dma(m_begin, 0);
+    auto run = [&](auto bias_tag) {
+        constexpr bool BIAS = decltype(bias_tag)::value;
+        for (int st = 0; st < nsteps; ++st) {
+            const int cur = st & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (st + 1 < nsteps) issue_dma(m_begin + (st + 1) * 64, cur ^ 1);
+            const int boff = cur * (2 * WT_TILE);
+            int ab[8], bb[4];
+#pragma unroll
+            for (int a = 0; a < 8; ++a) ab[a] = abase[a] + boff;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bb[c] = bbase[c] + boff;
+#pragma unroll
+            for (int ksub = 0; ksub < 2; ++ksub) {
+                bf16x8_t fb[4], fa[8];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int half = 0; half < 2; ++half)
+                        reinterpret_cast<s16x4_t*>(&fb[c])[half] = rd(bb[c] + ksub * 16384 + half * 4096);
+#pragma unroll
+                for (int a = 0; a < 8; ++a)
+#pragma unroll
+                    for (int half = 0; half < 2; ++half)
+                        reinterpret_cast<s16x4_t*>(&fa[a])[half] = rd(ab[a] + ksub * 16384 + half * 4096);
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[c], acc[a][c], 0, 0, 0);
+                    if constexpr (BIAS) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], ones, accb[a], 0, 0, 0);
+                }
+            }
+        }
+    };
+    if (do_bias) run(std::true_type{}); else run(std::false_type{});
+
+    float* out = slab_w + (long long)split * g.N * ktot;
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int col = col0 + wave_n * 64 + c * 16 + (lane & 15);
+            if (col >= ktot) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = co0 + wave_m * 128 + a * 16 + (lane >> 4) * 4 + j;
+                if (co < g.N) out[(long long)co * ktot + col] = acc[a][c][j];
+            }
+        }
+    if (do_bias && (lane & 15) == 0) {
+        float* ob = slab_b + (long long)split * g.N;
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = co0 + wave_m * 128 + a * 16 + (lane >> 4) * 4 + j;
+                if (co < g.N) ob[co] = accb[a][j];
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Weight gradient of a 3x3 / stride 1 / pad 1 convolution with LDS-resident tiles ("patch" form).
 // A workgroup owns 64 output channels x 64 input channels (one channel chunk) x all nine taps, and walks a range
 // of 16x16 output-pixel blocks.  Per block it brings in the dY tile [256 px][64 co] and the 18x18 halo patch of X
@@ -1772,7 +1961,7 @@ __global__ void k_head_grad_pack(const bf16_raw* __restrict__ dloc, const bf16_r
 struct Knob { const char* name; int value; bool init; };
 Knob g_knobs[] = {{"SSD_ABLATE", 0, false}, {"SSD_DGRAD_S2", 0, false}, {"SSD_CONV_VARIANT", 0, false}, {"SSD_CONV_PATCH", 0, false},
                   {"SSD_CONV_TILE", 0, false}, {"SSD_SPLITK", 0, false}, {"SSD_WGRAD_DMA", 0, false}, {"SSD_WGRAD_PATCH", 0, false},
-                  {"SSD_WGRAD_PATCH_SINGLE", 0, false}, {"SSD_WGRAD_PATCH_SHAPE", 0, false}};
+                  {"SSD_WGRAD_PATCH_SINGLE", 0, false}, {"SSD_WGRAD_PATCH_SHAPE", 0, false}, {"SSD_WGRAD_TILE", 0, false}};
 Knob* find_knob(const char* name) {
     for (Knob& k : g_knobs) if (!strcmp(k.name, name)) return &k;
     return nullptr;
@@ -2055,6 +2244,25 @@ static int wgrad_splits(long long M, int tiles) {
     return (int)want;
 }
 
+// 256x256 GEMM weight-gradient kernel: used for wide layers the patch kernel does not serve
+static bool wgrad_use_tile(long long M, int Cout, int ldy, long long ktot, long long x_elems) {
+    return knob("SSD_WGRAD_TILE", 1) && Cout > 128 && ktot >= 256 && M * ldy < (1ll << 31) - 16 && x_elems < (1ll << 31) - 16;
+}
+
+// pixel splits for that kernel (one workgroup per CU): estimated time = rounds x steps per split + slab traffic
+static int wgrad_tile_splits(long long M, int tiles, long long slab_elems) {
+    int best = 1;
+    double best_cost = 0;
+    const long long maxs = M / 256 > 0 ? M / 256 : 1;
+    for (int ns = 1; ns <= 64 && ns <= maxs; ++ns) {
+        const long long rounds = ((long long)tiles * ns + 255) / 256;
+        const long long steps = ((M + ns - 1) / ns + 63) / 64;
+        const double cost = (double)rounds * steps * 2.2 + (double)ns * slab_elems * 8.0 / 4.0e6;   // microseconds
+        if (ns == 1 || cost < best_cost) { best = ns; best_cost = cost; }
+    }
+    return best;
+}
+
 size_t ssd_conv2d_bwd_weight_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ldy, int ksize) {
     if (B <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || ldy < Cout || ksize <= 0) return 0;
     const long long ktot = (long long)ksize * ksize * Cin;
@@ -2068,7 +2276,13 @@ size_t ssd_conv2d_bwd_weight_workspace_bytes(int B, int Ho, int Wo, int Cin, int
     wgrad_tiles(Cout, ktot, &bmo, &bnc);
     const int tiles = (int)(((ktot + bnc - 1) / bnc) * ((Cout + bmo - 1) / bmo));
     const int ns = wgrad_splits((long long)B * Ho * Wo, tiles);
-    const size_t gen = (size_t)ns * ((size_t)ldy * ktot + ldy) * sizeof(float);
+    size_t gen = (size_t)ns * ((size_t)ldy * ktot + ldy) * sizeof(float);
+    if (Cout > 128 && ktot >= 256) {                          // the 256x256 GEMM kernel may serve the call
+        const int t2 = (int)(((ktot + 255) / 256) * ((Cout + 255) / 256));
+        const int ns2 = wgrad_tile_splits((long long)B * Ho * Wo, t2, (long long)ldy * ktot);
+        const size_t gen2 = (size_t)ns2 * ((size_t)ldy * ktot + ldy) * sizeof(float);
+        if (gen2 > gen) gen = gen2;
+    }
     return gen > patch_bytes ? gen : patch_bytes;
 }
 
@@ -2110,6 +2324,30 @@ int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias
 #undef SSD_LAUNCH_WP
         if (hipGetLastError() != hipSuccess) return SSD_ERR_LAUNCH;
         const long long nw = (long long)Cout * ktot;            // multiple of 4 (ktot = 9*Cin, Cin % 8 == 0)
+        const unsigned nbw = (unsigned)((nw / 4 + 255) / 256), nbb = dbias ? (unsigned)((Cout + 255) / 256) : 0u;
+        hipLaunchKernelGGL(k_wgrad_reduce2, dim3(nbw + nbb), dim3(256), 0, s, slab_w, (long long)ldy * ktot, nw, dw, slab_b,
+                           (long long)ldy, Cout, dbias, ns, nbw);
+        return ssd_launch_status();
+    }
+    if (wgrad_use_tile(g.M, Cout, ldy, ktot, (long long)B * H * W * Cin)) {
+        const int ctiles = (int)((ktot + 255) / 256), mtiles = (Cout + 255) / 256;
+        const int ns = wgrad_tile_splits(g.M, ctiles * mtiles, (long long)ldy * ktot);
+        int mps = (int)(((long long)g.M + ns - 1) / ns);
+        mps = (mps + 63) / 64 * 64;
+        float* slab_w = static_cast<float*>(ws);
+        float* slab_b = slab_w + (size_t)ns * ldy * ktot;
+        hipStream_t s = (hipStream_t)stream;
+        static bool set = false;
+        if (!set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad_tile), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    4 * WT_TILE) != hipSuccess) return SSD_ERR_LAUNCH;
+            set = true;
+        }
+        hipLaunchKernelGGL(k_conv_wgrad_tile, dim3(ctiles * mtiles * ns), dim3(512), 4 * WT_TILE, s,
+                           static_cast<const bf16_raw*>(x), static_cast<const bf16_raw*>(dy), slab_w, dbias ? slab_b : nullptr, g,
+                           mps, ns, Cout);
+        if (hipGetLastError() != hipSuccess) return SSD_ERR_LAUNCH;
+        const long long nw = (long long)Cout * ktot;
         const unsigned nbw = (unsigned)((nw / 4 + 255) / 256), nbb = dbias ? (unsigned)((Cout + 255) / 256) : 0u;
         hipLaunchKernelGGL(k_wgrad_reduce2, dim3(nbw + nbb), dim3(256), 0, s, slab_w, (long long)ldy * ktot, nw, dw, slab_b,
                            (long long)ldy, Cout, dbias, ns, nbw);

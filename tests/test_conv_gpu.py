@@ -47,6 +47,9 @@ CASES = [
     (3, 19, 19, 128, 64, 3, 2, "same"),      # stride-2 data gradient by parity classes (odd size, pad (1,1))
     (2, 19, 19, 128, 192, 3, 1, "same"),     # weight gradient with 10x24 blocks (the 19x19 maps)
     (1, 25, 20, 64, 64, 3, 1, "same"),       # 10x24 blocks, partial in both dims
+    (3, 19, 19, 256, 320, 1, 1, "same"),     # 256x256 GEMM weight gradient, pointwise, ragged channel tile
+    (2, 21, 21, 64, 264, 3, 2, "same"),      # 256x256 GEMM weight gradient, strided 3x3 (taps inside a column tile)
+    (5, 3, 3, 128, 256, 3, 1, "valid"),      # 256x256 GEMM weight gradient, VALID, tiny M
 ]
 
 

@@ -12,7 +12,8 @@ rounds = int(sys.argv[10]) if len(sys.argv) > 10 else 7
 L = _lib.lib()
 torch.manual_seed(0)
 x = torch.relu(torch.randn((B, H, H, Cin), device="cuda")).bfloat16()
-Ho, pt = ops.same_pad(H, k, 1)
+S = int(os.environ.get("AB_STRIDE", "1"))
+Ho, pt = ops.same_pad(H, k, S)
 if mode == "fwd":
     w = (torch.randn((Cout, k, k, Cin), device="cuda") * 0.05).bfloat16(); b = torch.zeros(Cout, device="cuda")
     y = ops.conv2d_fwd(x, w, b, 1, pt, pt, Ho, Ho, True)
@@ -24,9 +25,9 @@ elif mode == "head":
     loc = torch.empty((B, A, 4), device="cuda", dtype=torch.bfloat16); conf = torch.empty((B, A, 81), device="cuda", dtype=torch.bfloat16)
     run = lambda: ops.conv2d_head_fwd(x, w, b, loc, conf, per_cell, 81, 0)
 elif mode == "wgrad":
-    dy = torch.randn((B, H, H, Cout), device="cuda").bfloat16()
-    dw, db = ops.conv2d_bwd_weight(x, dy, Cout, k, 1, pt, pt)
-    run = lambda: ops.conv2d_bwd_weight(x, dy, Cout, k, 1, pt, pt, dw=dw, dbias=db)
+    dy = torch.randn((B, Ho, Ho, Cout), device="cuda").bfloat16()
+    dw, db = ops.conv2d_bwd_weight(x, dy, Cout, k, S, pt, pt)
+    run = lambda: ops.conv2d_bwd_weight(x, dy, Cout, k, S, pt, pt, dw=dw, dbias=db)
 else:
     # data gradient of a Cin->Cout conv: dy [B,H,H,Cout], w_t [Cin][k][k][Cout]
     dy = torch.randn((B, H, H, Cout), device="cuda").bfloat16()

@@ -1031,6 +1031,134 @@ __global__ __launch_bounds__(512) void k_conv3x3_patch(const bf16_raw* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// Second form of the LDS-patch kernel (default): 32-channel chunks, linear padded images, two workgroups per CU.
+//   * patch image: one 96-byte row per halo pixel (64 B of channels + 32 B pad).  The pitch makes every shifted
+//     ds_read_b128 conflict-free WITHOUT an address swizzle, so a fragment address is a per-lane base + immediate
+//     (the swizzled 128-byte rows of the first form cost ~10 VALU per read and were 2-way conflicted for 3 of 4 shifts);
+//   * weight slice of a tap: [BN][32 k] in 64-byte rows, chunk XORed with (-(row >> 2)) & 3 (conflict-free, fixed rows);
+//   * all DMA through buffer descriptors: per-lane byte offsets are computed once, the (tap, chunk) part is a scalar
+//     offset, invalid / padding lanes are out of range (zeros): no vector arithmetic per DMA in the loop;
+//   * 80 KB of LDS (two patch buffers, two weight buffers) and <= 128 VGPRs: two workgroups per CU cover each other's
+//     prologue, barriers and store tail; the next chunk's patch is prefetched at the first tap of the current one and
+//     left in flight across the barrier (counted vmcnt).
+constexpr int P32_PITCH = 96;
+constexpr int P32_PATCH = 32 * 1024;                       // 324 px x 96 B = 31104 B, rounded to 32 DMA instructions
+
+template <int BN, int EPI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_conv3x3_patch32(
+    const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ w, ConvGeom g, Epilogue ep, int tiles_x, int tiles_y) {
+    constexpr int CT = BN / 32;
+    constexpr int PT = 4;
+    constexpr int WBYTES = BN * 64;                          // weight slice of one tap
+    constexpr int OFF_W = 2 * P32_PATCH;
+    constexpr int OFF_DUMMY = OFF_W + 2 * WBYTES;            // BN = 64: waves 4-7 have no weight rows, their DMA lands here
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave & 3, wave_n = wave >> 2;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int y0 = ty * 16, x0 = tx * 16, n0 = blockIdx.y * BN;
+
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (unsigned)g.B * g.H * g.W * g.C * 2u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (unsigned)g.N * (unsigned)g.ldw * 2u, 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;
+    // patch DMA: instruction i = wave + 8j (j < 4) fills slots 64i .. 64i+63; slot q -> pixel q / 6, 16-byte piece q % 6
+    unsigned pvo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = (wave + 8 * j) * 64 + lane;
+        const int pp = q / 6, sl = q - pp * 6;
+        const int py = pp / PATCH_W, px = pp - py * PATCH_W;
+        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+        const bool ok = sl < 4 && pp < PATCH_PIX && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+        pvo[j] = ok ? ((unsigned)((b * g.H + iy) * g.W + ix) * (unsigned)g.C + (unsigned)(sl * 8)) * 2u : OOB;
+    }
+    // weight DMA: instruction i = wave (< BN/16) fills rows 16i .. 16i+15; lane L -> row 16i + (L>>2), physical piece L & 3
+    unsigned wvo;
+    {
+        const int row = 16 * wave + (lane >> 2);
+        const int piece = (lane & 3) ^ ((-(row >> 2)) & 3);
+        const int n = n0 + row;
+        wvo = (row < BN && n < g.N) ? ((unsigned)n * (unsigned)g.ldw + (unsigned)(piece * 8)) * 2u : OOB;
+    }
+    const int wdst = wave < BN / 16 ? wave * 1024 : -1;     // -1: dummy
+    const int nchunk = g.C >> 5;
+
+    auto dma_patch = [&](int chunk, int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)(smem + buf * P32_PATCH + (wave + 8 * j) * 1024), 16, pvo[j],
+                                                     chunk * 64, 0, 0);
+    };
+    auto dma_w = [&](int chunk, int tap, int buf) {
+        char* dst = wdst >= 0 ? smem + OFF_W + buf * WBYTES + wdst : smem + OFF_DUMMY;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_void*)dst, 16, wvo, (tap * g.C + chunk * 32) * 2, 0, 0);
+    };
+
+    f32x4_t acc[CT][PT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int p = 0; p < PT; ++p) acc[c][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fk = lane >> 4;
+    const int xbase = (4 * wave_m * PATCH_W + frow) * P32_PITCH + fk * 16;
+    int wbase;
+    {
+        const int row = wave_n * (16 * CT) + frow;
+        wbase = OFF_W + row * 64 + ((fk ^ ((-(row >> 2)) & 3)) << 4);
+    }
+    auto ldf = [&](int addr) { return *reinterpret_cast<const bf16x8_t*>(smem + addr); };
+
+    dma_patch(0, 0);
+    dma_w(0, 0, 0);
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        const int pb = (chunk & 1) * P32_PATCH;
+        const bool next_chunk = chunk + 1 < nchunk;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int wb = ((chunk + tap) & 1) * WBYTES;    // step s = 9 chunk + tap: s & 1 == (chunk + tap) & 1
+            // this step's weight slice has landed (the patch prefetch issued after it at tap 0 may still be in flight)
+            if (tap == 1 && next_chunk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (tap < 8) dma_w(chunk, tap + 1, ((chunk + tap + 1) & 1));
+            else if (next_chunk) dma_w(chunk + 1, 0, ((chunk + tap + 1) & 1));
+            if (tap == 0 && next_chunk) dma_patch(chunk + 1, (chunk + 1) & 1);
+            bf16x8_t fx[PT], fw[CT];
+#pragma unroll
+            for (int p = 0; p < PT; ++p) fx[p] = ldf(pb + xbase + ((p + tap / 3) * PATCH_W + tap % 3) * P32_PITCH);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) fw[c] = ldf(wb + wbase + c * 1024);
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int p = 0; p < PT; ++p)
+                    acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[c], fx[p], acc[c][p], 0, 0, 0);
+        }
+    }
+    if (staged_ok<EPI>(g, ep) && !(g.ablate & 8)) {          // tile image [256 block pixels][BN] in the (now idle) patch buffers
+        auto row_to_m = [&](int row) {
+            const int y = y0 + (row >> 4), xx = x0 + (row & 15);
+            return (y < g.Ho && xx < g.Wo) ? (b * g.Ho + y) * g.Wo + xx : -1;
+        };
+        staged_epilogue<EPI, 256, BN, CT, PT, 512>(acc, smem, g, ep, n0, wave_m * 64, wave_n * (16 * CT), tid, row_to_m);
+        return;
+    }
+    int mrow[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const int y = y0 + 4 * wave_m + p, xx = x0 + (lane & 15);
+        mrow[p] = (y < g.Ho && xx < g.Wo) ? (b * g.Ho + y) * g.Wo + xx : -1;
+    }
+    conv_epilogue_rows<EPI, CT, PT>(acc, g, ep, mrow, n0 + wave_n * (16 * CT), lane);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Weight gradient.  grid (col tiles, co tiles, splits).  Per step 64 pixels.
 constexpr int WG_LD = 288;                   // LDS row stride (bytes) of a [pixel][128 ch] tile: 256 + 32 pad
 
@@ -1961,7 +2089,7 @@ __global__ void k_head_grad_pack(const bf16_raw* __restrict__ dloc, const bf16_r
 struct Knob { const char* name; int value; bool init; };
 Knob g_knobs[] = {{"SSD_ABLATE", 0, false}, {"SSD_DGRAD_S2", 0, false}, {"SSD_CONV_VARIANT", 0, false}, {"SSD_CONV_PATCH", 0, false},
                   {"SSD_CONV_TILE", 0, false}, {"SSD_SPLITK", 0, false}, {"SSD_WGRAD_DMA", 0, false}, {"SSD_WGRAD_PATCH", 0, false},
-                  {"SSD_WGRAD_PATCH_SINGLE", 0, false}, {"SSD_WGRAD_PATCH_SHAPE", 0, false}, {"SSD_WGRAD_TILE", 0, false}};
+                  {"SSD_WGRAD_PATCH_SINGLE", 0, false}, {"SSD_WGRAD_PATCH_SHAPE", 0, false}, {"SSD_WGRAD_TILE", 0, false}, {"SSD_CONV_PATCH_FORM", 0, false}};
 Knob* find_knob(const char* name) {
     for (Knob& k : g_knobs) if (!strcmp(k.name, name)) return &k;
     return nullptr;
@@ -2013,6 +2141,23 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
         g.C % 64 == 0 && g.H == g.Ho && g.W == g.Wo && g.N <= use_patch && g.H >= 16 && g.W >= 16) {
         const int tiles_x = (g.Wo + 15) / 16, tiles_y = (g.Ho + 15) / 16;
         const unsigned gx = (unsigned)(tiles_x * tiles_y * g.B);
+        if (knob("SSD_CONV_PATCH_FORM", 2) >= 2 && (long long)g.B * g.H * g.W * g.C < (1ll << 31) - 16 &&
+            (long long)g.N * g.ldw < (1ll << 31) - 16) {
+            if (g.N <= 64) {
+                constexpr int lds = 2 * P32_PATCH + 2 * 64 * 64 + 1024;
+                auto kern = k_conv3x3_patch32<64, EPI>;
+                static bool set = false;
+                if (!set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return SSD_ERR_LAUNCH; set = true; }
+                hipLaunchKernelGGL(kern, dim3(gx, (unsigned)((g.N + 63) / 64)), dim3(512), lds, s, xp, wp, g, ep, tiles_x, tiles_y);
+            } else {
+                constexpr int lds = 2 * P32_PATCH + 2 * 128 * 64;
+                auto kern = k_conv3x3_patch32<128, EPI>;
+                static bool set = false;
+                if (!set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return SSD_ERR_LAUNCH; set = true; }
+                hipLaunchKernelGGL(kern, dim3(gx, (unsigned)((g.N + 127) / 128)), dim3(512), lds, s, xp, wp, g, ep, tiles_x, tiles_y);
+            }
+            return ssd_launch_status();
+        }
         if (g.N <= 64) {
             const size_t lds = 2 * 64 * 128 + PATCH_BYTES;
             auto kern = k_conv3x3_patch<64, EPI>;
@@ -2246,7 +2391,8 @@ static int wgrad_splits(long long M, int tiles) {
 
 // 256x256 GEMM weight-gradient kernel: used for wide layers the patch kernel does not serve
 static bool wgrad_use_tile(long long M, int Cout, int ldy, long long ktot, long long x_elems) {
-    return knob("SSD_WGRAD_TILE", 1) && Cout > 128 && ktot >= 256 && M * ldy < (1ll << 31) - 16 && x_elems < (1ll << 31) - 16;
+    return knob("SSD_WGRAD_TILE", 1) && Cout > 128 && ktot >= 256 && M >= 2048 && M * ldy < (1ll << 31) - 16 &&
+           x_elems < (1ll << 31) - 16;
 }
 
 // pixel splits for that kernel (one workgroup per CU): estimated time = rounds x steps per split + slab traffic

@@ -178,6 +178,20 @@ def main():
         dist.destroy_process_group()
 
 
+
+def _usable_cores():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box exposes all of
+    the host's CPUs but grants a share of them; more threads than that only thrash)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
 def cpu_baseline(np, torch):
     """The oracle port of the same step on the host cores, on a bounded sample: anchor matching by the literal C
     restatement of utils/bbox.py (one thread, as the reference's generator is), network forward/backward by the
@@ -186,7 +200,7 @@ def cpu_baseline(np, torch):
     from ssd_object_detection_amd.engine import SSD300_TRUNK, SSD300_NUM_PRIORS
     from ssd_object_detection_amd.data_loaders.synthetic import synth_batch_gt
     import math
-    cores = os.cpu_count() or 1
+    cores = _usable_cores()
     torch.set_num_threads(cores)
     Bc = 4
     pri = O.priors()

@@ -2136,9 +2136,12 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
     ep.slab = nullptr;
     ep.ksplit = 1;
     const unsigned gm = (unsigned)((g.M + 127) / 128);
-    const int use_patch = knob("SSD_CONV_PATCH", 128);   // max N served
+    // LDS-patch kernel: 3x3 / stride 1 / pad 1 with N <= SSD_CONV_PATCH (default 256); beyond 128 channels only when
+    // the 16x16 blocks waste little of the map (75x75 and larger: <= 14 %; 38x38 would waste 37 %)
+    const int use_patch = knob("SSD_CONV_PATCH", 256);
+    const bool patch_fits = g.N <= 128 || (long long)((g.Wo + 15) / 16) * ((g.Ho + 15) / 16) * 256 * 4 <= (long long)g.Wo * g.Ho * 5;
     if (igemm_variant() >= 1 && g.KH == 3 && g.KW == 3 && g.mul == 1 && g.div == 1 && g.pad_t == 1 && g.pad_l == 1 &&
-        g.C % 64 == 0 && g.H == g.Ho && g.W == g.Wo && g.N <= use_patch && g.H >= 16 && g.W >= 16) {
+        g.C % 64 == 0 && g.H == g.Ho && g.W == g.Wo && g.N <= use_patch && patch_fits && g.H >= 16 && g.W >= 16) {
         const int tiles_x = (g.Wo + 15) / 16, tiles_y = (g.Ho + 15) / 16;
         const unsigned gx = (unsigned)(tiles_x * tiles_y * g.B);
         if (knob("SSD_CONV_PATCH_FORM", 2) >= 2 && (long long)g.B * g.H * g.W * g.C < (1ll << 31) - 16 &&

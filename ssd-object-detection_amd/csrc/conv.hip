@@ -1044,7 +1044,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_patch(const bf16_raw* __restric
 constexpr int P32_PITCH = 96;
 constexpr int P32_PATCH = 32 * 1024;                       // 324 px x 96 B = 31104 B, rounded to 32 DMA instructions
 
-template <int BN, int EPI>
+template <int BN, int EPI, bool FLAT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_conv3x3_patch32(
     const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ w, ConvGeom g, Epilogue ep, int tiles_x, int tiles_y) {
     constexpr int CT = BN / 32;
@@ -1057,11 +1057,33 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave & 3, wave_n = wave >> 2;
-    int t = blockIdx.x;
-    const int tx = t % tiles_x; t /= tiles_x;
-    const int ty = t % tiles_y;
-    const int b = t / tiles_y;
-    const int y0 = ty * 16, x0 = tx * 16, n0 = blockIdx.y * BN;
+    // two block shapes.  flat == 0: a 16x16 block of one image, halo patch 18x18 (tap pitch Q = 18).
+    // flat != 0 (narrow maps): the batch is one long strip of positions, image rows padded to Q = W + 2 (a zero column
+    // on either side) and images separated by ONE zero row; a block is 256 consecutive positions, its patch those plus
+    // Q + 1 on either side, tap (kh,kw) is position + kh*Q + kw.  Pad positions are computed and dropped: 7 % of the
+    // work at 38x38 and 14 % at 19x19, where 16x16 blocks would waste 37 % and 65 %.
+    const int n0 = blockIdx.y * BN;
+    constexpr bool flat = FLAT;
+    const int Q = FLAT ? g.W + 2 : PATCH_W;
+    const int img = (g.H + 1) * Q;                          // flat positions per image
+    int b = 0, y0 = 0, x0 = 0, f0 = 0;
+    if constexpr (FLAT) {
+        f0 = blockIdx.x * 256;
+    } else {
+        int t = blockIdx.x;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y;
+        b = t / tiles_y;
+        y0 = ty * 16; x0 = tx * 16;
+    }
+    // flat position -> source pixel (element offset / C) or -1
+    auto flat_pixel = [&](int f) {
+        if (f < 0) return -1;
+        const int bb = f / img;
+        const int r = f - bb * img;
+        const int yy = r / Q, xx = r - yy * Q - 1;
+        return (bb < g.B && yy < g.H && (unsigned)xx < (unsigned)g.W) ? (bb * g.H + yy) * g.W + xx : -1;
+    };
 
     const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (unsigned)g.B * g.H * g.W * g.C * 2u, 0x00020000);
     const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (unsigned)g.N * (unsigned)g.ldw * 2u, 0x00020000);
@@ -1072,10 +1094,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int j = 0; j < 4; ++j) {
         const int q = (wave + 8 * j) * 64 + lane;
         const int pp = q / 6, sl = q - pp * 6;
-        const int py = pp / PATCH_W, px = pp - py * PATCH_W;
-        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-        const bool ok = sl < 4 && pp < PATCH_PIX && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
-        pvo[j] = ok ? ((unsigned)((b * g.H + iy) * g.W + ix) * (unsigned)g.C + (unsigned)(sl * 8)) * 2u : OOB;
+        int pix;
+        if (flat) {
+            pix = pp < 256 + 2 * (Q + 1) ? flat_pixel(f0 - (Q + 1) + pp) : -1;
+        } else {
+            const int py = pp / PATCH_W, px = pp - py * PATCH_W;
+            const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+            pix = (pp < PATCH_PIX && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W) ? (b * g.H + iy) * g.W + ix : -1;
+        }
+        pvo[j] = (sl < 4 && pix >= 0) ? ((unsigned)pix * (unsigned)g.C + (unsigned)(sl * 8)) * 2u : OOB;
     }
     // weight DMA: instruction i = wave (< BN/16) fills rows 16i .. 16i+15; lane L -> row 16i + (L>>2), physical piece L & 3
     unsigned wvo;
@@ -1106,7 +1133,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int p = 0; p < PT; ++p) acc[c][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fk = lane >> 4;
-    const int xbase = (4 * wave_m * PATCH_W + frow) * P32_PITCH + fk * 16;
+    const int xbase = (flat ? 4 * wave_m * 16 + frow : 4 * wave_m * PATCH_W + frow) * P32_PITCH + fk * 16;
+    constexpr int prow = (FLAT ? 16 : PATCH_W) * P32_PITCH;  // bytes between the pixel tiles p, p+1 of a wave
     int wbase;
     {
         const int row = wave_n * (16 * CT) + frow;
@@ -1130,8 +1158,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             else if (next_chunk) dma_w(chunk + 1, 0, ((chunk + tap + 1) & 1));
             if (tap == 0 && next_chunk) dma_patch(chunk + 1, (chunk + 1) & 1);
             bf16x8_t fx[PT], fw[CT];
+            const int tapoff = pb + xbase + ((tap / 3) * Q + tap % 3) * P32_PITCH;
 #pragma unroll
-            for (int p = 0; p < PT; ++p) fx[p] = ldf(pb + xbase + ((p + tap / 3) * PATCH_W + tap % 3) * P32_PITCH);
+            for (int p = 0; p < PT; ++p) fx[p] = ldf(tapoff + p * prow);
 #pragma unroll
             for (int c = 0; c < CT; ++c) fw[c] = ldf(wb + wbase + c * 1024);
 #pragma unroll
@@ -1143,6 +1172,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     if (staged_ok<EPI>(g, ep) && !(g.ablate & 8)) {          // tile image [256 block pixels][BN] in the (now idle) patch buffers
         auto row_to_m = [&](int row) {
+            if (flat) return flat_pixel(f0 + row);
             const int y = y0 + (row >> 4), xx = x0 + (row & 15);
             return (y < g.Ho && xx < g.Wo) ? (b * g.Ho + y) * g.Wo + xx : -1;
         };
@@ -1152,8 +1182,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     int mrow[PT];
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
-        const int y = y0 + 4 * wave_m + p, xx = x0 + (lane & 15);
-        mrow[p] = (y < g.Ho && xx < g.Wo) ? (b * g.Ho + y) * g.Wo + xx : -1;
+        if (flat) {
+            mrow[p] = flat_pixel(f0 + (4 * wave_m + p) * 16 + (lane & 15));
+        } else {
+            const int y = y0 + 4 * wave_m + p, xx = x0 + (lane & 15);
+            mrow[p] = (y < g.Ho && xx < g.Wo) ? (b * g.Ho + y) * g.Wo + xx : -1;
+        }
     }
     conv_epilogue_rows<EPI, CT, PT>(acc, g, ep, mrow, n0 + wave_n * (16 * CT), lane);
 }
@@ -2089,7 +2123,7 @@ __global__ void k_head_grad_pack(const bf16_raw* __restrict__ dloc, const bf16_r
 struct Knob { const char* name; int value; bool init; };
 Knob g_knobs[] = {{"SSD_ABLATE", 0, false}, {"SSD_DGRAD_S2", 0, false}, {"SSD_CONV_VARIANT", 0, false}, {"SSD_CONV_PATCH", 0, false},
                   {"SSD_CONV_TILE", 0, false}, {"SSD_SPLITK", 0, false}, {"SSD_WGRAD_DMA", 0, false}, {"SSD_WGRAD_PATCH", 0, false},
-                  {"SSD_WGRAD_PATCH_SINGLE", 0, false}, {"SSD_WGRAD_PATCH_SHAPE", 0, false}, {"SSD_WGRAD_TILE", 0, false}, {"SSD_CONV_PATCH_FORM", 0, false}};
+                  {"SSD_WGRAD_PATCH_SINGLE", 0, false}, {"SSD_WGRAD_PATCH_SHAPE", 0, false}, {"SSD_WGRAD_TILE", 0, false}, {"SSD_CONV_PATCH_FORM", 0, false}, {"SSD_CONV_PATCH_FLAT", 0, false}};
 Knob* find_knob(const char* name) {
     for (Knob& k : g_knobs) if (!strcmp(k.name, name)) return &k;
     return nullptr;
@@ -2140,25 +2174,32 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
     // the 16x16 blocks waste little of the map (75x75 and larger: <= 14 %; 38x38 would waste 37 %)
     const int use_patch = knob("SSD_CONV_PATCH", 256);
     const bool patch_fits = g.N <= 128 || (long long)((g.Wo + 15) / 16) * ((g.Ho + 15) / 16) * 256 * 4 <= (long long)g.Wo * g.Ho * 5;
+    // narrow maps (patch of 256 + 2 (W + 3) positions fits 32 KB): strip blocks, any channel count
+    const int flat_knob = knob("SSD_CONV_PATCH_FLAT", 1);
+    const bool use_flat = flat_knob && g.W <= 39 && g.W >= 16 && g.H >= 16 && (flat_knob >= 2 || !patch_fits || g.N > use_patch);
     if (igemm_variant() >= 1 && g.KH == 3 && g.KW == 3 && g.mul == 1 && g.div == 1 && g.pad_t == 1 && g.pad_l == 1 &&
-        g.C % 64 == 0 && g.H == g.Ho && g.W == g.Wo && g.N <= use_patch && patch_fits && g.H >= 16 && g.W >= 16) {
+        g.C % 64 == 0 && g.H == g.Ho && g.W == g.Wo && ((g.N <= use_patch && patch_fits) || use_flat) && g.H >= 16 && g.W >= 16) {
         const int tiles_x = (g.Wo + 15) / 16, tiles_y = (g.Ho + 15) / 16;
         const unsigned gx = (unsigned)(tiles_x * tiles_y * g.B);
         if (knob("SSD_CONV_PATCH_FORM", 2) >= 2 && (long long)g.B * g.H * g.W * g.C < (1ll << 31) - 16 &&
             (long long)g.N * g.ldw < (1ll << 31) - 16) {
-            if (g.N <= 64) {
-                constexpr int lds = 2 * P32_PATCH + 2 * 64 * 64 + 1024;
-                auto kern = k_conv3x3_patch32<64, EPI>;
-                static bool set = false;
-                if (!set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return SSD_ERR_LAUNCH; set = true; }
-                hipLaunchKernelGGL(kern, dim3(gx, (unsigned)((g.N + 63) / 64)), dim3(512), lds, s, xp, wp, g, ep, tiles_x, tiles_y);
-            } else {
-                constexpr int lds = 2 * P32_PATCH + 2 * 128 * 64;
-                auto kern = k_conv3x3_patch32<128, EPI>;
-                static bool set = false;
-                if (!set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return SSD_ERR_LAUNCH; set = true; }
-                hipLaunchKernelGGL(kern, dim3(gx, (unsigned)((g.N + 127) / 128)), dim3(512), lds, s, xp, wp, g, ep, tiles_x, tiles_y);
-            }
+            const bool flat = use_flat;
+            const unsigned gxx = flat ? (unsigned)(((long long)g.B * (g.H + 1) * (g.W + 2) + 255) / 256) : gx;
+#define SSD_LAUNCH_P32(BN_, FLAT_)                                                                                  \
+            do {                                                                                                    \
+                constexpr int lds_ = 2 * P32_PATCH + 2 * BN_ * 64 + (BN_ == 64 ? 1024 : 0);                         \
+                auto kern_ = k_conv3x3_patch32<BN_, EPI, FLAT_>;                                                    \
+                static bool set_ = false;                                                                           \
+                if (!set_) {                                                                                        \
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, lds_) != hipSuccess) \
+                        return SSD_ERR_LAUNCH;                                                                      \
+                    set_ = true;                                                                                    \
+                }                                                                                                   \
+                hipLaunchKernelGGL(kern_, dim3(gxx, (unsigned)((g.N + BN_ - 1) / BN_)), dim3(512), lds_, s, xp, wp, g, ep, tiles_x, tiles_y); \
+            } while (0)
+            if (g.N <= 64) { if (flat) SSD_LAUNCH_P32(64, true); else SSD_LAUNCH_P32(64, false); }
+            else { if (flat) SSD_LAUNCH_P32(128, true); else SSD_LAUNCH_P32(128, false); }
+#undef SSD_LAUNCH_P32
             return ssd_launch_status();
         }
         if (g.N <= 64) {

@@ -50,6 +50,8 @@ CASES = [
     (3, 19, 19, 256, 320, 1, 1, "same"),     # 256x256 GEMM weight gradient, pointwise, ragged channel tile
     (2, 21, 21, 64, 264, 3, 2, "same"),      # 256x256 GEMM weight gradient, strided 3x3 (taps inside a column tile)
     (5, 3, 3, 128, 256, 3, 1, "valid"),      # 256x256 GEMM weight gradient, VALID, tiny M
+    (2, 38, 38, 64, 192, 3, 1, "same"),      # LDS-patch kernel on strip blocks (narrow map, N > 128)
+    (3, 19, 19, 128, 320, 3, 1, "same"),     # strip blocks spanning images, two channel chunks x three channel tiles
 ]
 
 
@@ -108,6 +110,36 @@ def test_conv_fwd_bwd(ops, case):
     # deterministic
     dw2, _ = ops.conv2d_bwd_weight(xd, dyd, Cout, k, stride, pt, pl)
     assert torch.equal(dw, dw2)
+
+
+@pytest.mark.parametrize("case", [(2, 30, 30, 64, 64), (3, 17, 23, 128, 96), (1, 38, 38, 64, 136)])
+def test_patch_strip_blocks_forced(ops, case):
+    """Strip blocks (SSD_CONV_PATCH_FLAT=2 forces them wherever the map is narrow enough) give the same forward and
+    data gradient as the 16x16 blocks: the block shape is a tuning choice only."""
+    from ssd_object_detection_amd import _lib
+    B, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((B, H, W, Cin), generator=g).bfloat16()
+    w = (torch.randn((Cout, 3, 3, Cin), generator=g) / np.sqrt(9 * Cin)).bfloat16()
+    bias = torch.randn((Cout,), generator=g) * 0.1
+    dy = torch.randn((B, H, W, Cout), generator=g).bfloat16()
+    L = _lib.lib()
+    outs = []
+    for flat in (0, 2):
+        assert L.ssd_dev_knob(b"SSD_CONV_PATCH_FLAT", flat) == 0
+        try:
+            y = ops.conv2d_fwd(x.cuda(), w.cuda(), bias.cuda(), 1, 1, 1, H, W, True)
+            dx = ops.conv2d_bwd_data(dy.cuda(), ops.weight_transpose(w.cuda()), x.cuda(), (B, H, W, Cin), 1, 1, 1)
+        finally:
+            L.ssd_dev_knob(b"SSD_CONV_PATCH_FLAT", 1)
+        outs.append((y.float().cpu(), dx.float().cpu()))
+    yr = ref_conv(x.float(), w.float(), bias, 3, 1, 1, 1, H, W, True)
+    assert (outs[1][0] - yr).abs().max().item() <= 2 ** -7 * max(1.0, yr.abs().max().item())
+    if Cout <= 128:     # both runs use the patch kernel, same k order -> bitwise equal
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    else:               # the unforced run used the generic implicit GEMM (other summation order)
+        assert (outs[0][0] - outs[1][0]).abs().max().item() <= 2 ** -7 * max(1.0, yr.abs().max().item())
+        assert (outs[0][1] - outs[1][1]).abs().max().item() <= 2 ** -7 * max(1.0, outs[0][1].abs().max().item())
 
 
 @pytest.mark.parametrize("shape", [0, 1, 2])

@@ -9,6 +9,7 @@ The 3-channel image is carried in 8 zero-padded channels (first-layer weights of
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -64,6 +65,8 @@ class SSDEngine:
         self.init_params(seed)
         self._act_cache = {}
         self._ws = ops.MatchWorkspace()
+        self._side = None
+        self.overlap_heads = os.environ.get("SSD_OVERLAP_HEADS", "1") != "0" and self.device.type == "cuda"
         self.step_count = 0
 
     # ---------------------------------------------------------------- static planning
@@ -205,12 +208,34 @@ class SSDEngine:
         return c
 
     # ---------------------------------------------------------------- forward / backward
+    # Two HIP streams.  The two large heads (38x38 and 19x19 maps) are independent of the small tail of the network
+    # (conv 12-19 and heads 2-5: ~45 short, latency-bound launches that leave most CUs idle), so they run on a side
+    # stream next to it, forward and backward; results do not depend on this (disjoint outputs, the one shared
+    # accumulation target is ordered by an event).
+    SIDE_HEADS = (0, 1)
+
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._ws_side = ops.MatchWorkspace()
+        return self._side
+
     def forward(self, x):
         """x: bf16 [B, S, S, 8] (ops.image_prep).  Returns (loc bf16 [B,A,4], conf bf16 [B,A,classes])."""
         B = x.shape[0]
         c = self._acts(B)
         acts = c["acts"]
         acts[0] = x
+        main = torch.cuda.current_stream()
+        side = self._side_stream() if self.overlap_heads else None
+        fm_level = {ni: lvl for lvl, (ni, _, _) in enumerate(self.fm)}
+
+        def head(lvl, ws):
+            ni = self.fm[lvl][0]
+            wt, bt = self.head_params[lvl]
+            ops.conv2d_head_fwd(acts[ni + 1], self.view(wt, self.param_bf16), self.view(bt, self.param), c["loc"],
+                                c["conf"], self.num_priors[lvl], self.classes, self.level_off[lvl], ws=ws)
+
         for i, nd in enumerate(self.nodes):
             if nd["kind"] == "conv":
                 wt, bt = self.conv_params[i]
@@ -220,10 +245,18 @@ class SSDEngine:
                 L = self.L
                 _lib.check(L.ssd_maxpool2x2_fwd(ops._ptr(acts[i]), ops._ptr(acts[i + 1]), B, nd["hin"], nd["hin"],
                                                 nd["cin"], nd["hout"], nd["hout"], ops._stream()))
-        for lvl, (ni, h, ch) in enumerate(self.fm):
-            wt, bt = self.head_params[lvl]
-            ops.conv2d_head_fwd(acts[ni + 1], self.view(wt, self.param_bf16), self.view(bt, self.param), c["loc"],
-                                c["conf"], self.num_priors[lvl], self.classes, self.level_off[lvl], ws=self._ws)
+            lvl = fm_level.get(i)
+            if side is not None and lvl in self.SIDE_HEADS:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    head(lvl, self._ws_side)
+        for lvl in range(len(self.fm)):
+            if side is None or lvl not in self.SIDE_HEADS:
+                head(lvl, self._ws)
+        if side is not None:
+            main.wait_stream(side)
         return c["loc"], c["conf"]
 
     def backward(self, dloc, dconf, on_ready=None):
@@ -233,22 +266,55 @@ class SSDEngine:
         c = self._acts(B)
         acts, gacts = c["acts"], c["gacts"]
         written = [False] * len(acts)
-        # heads: weight gradients and their contribution to the feature-map gradients
-        for lvl, (ni, h, ch) in enumerate(self.fm):
+        main = torch.cuda.current_stream()
+        side = self._side_stream() if self.overlap_heads else None
+
+        def head(lvl, ws):
+            ni, h, ch = self.fm[lvl]
             n = self.num_priors[lvl]
             packed = ops.head_grad_pack(dloc, dconf, h * h, n, self.classes, self.head_npad[lvl], self.level_off[lvl],
                                         out=c["packed"][lvl]).view(B, h, h, self.head_npad[lvl])
             wt, bt = self.head_params[lvl]
             ops.conv2d_bwd_weight(acts[ni + 1], packed, wt.shape[0], 3, 1, 1, 1, dw=self.view(wt, self.grad),
-                                  dbias=self.view(bt, self.grad), ws=self._ws)
-            if on_ready:
-                on_ready([wt.index, bt.index])
+                                  dbias=self.view(bt, self.grad), ws=ws)
             ops.conv2d_bwd_data(packed, self.head_w_t[lvl], acts[ni + 1], acts[ni + 1].shape, 1, 1, 1,
-                                accumulate=False, out=gacts[ni + 1], ws=self._ws)
+                                accumulate=False, out=gacts[ni + 1], ws=ws)
             written[ni + 1] = True
+            return [wt.index, bt.index]
+
+        # heads: weight gradients and their contribution to the feature-map gradients.  The side-stream heads are joined
+        # (and reported ready) right before the first launch that accumulates into the same feature-map gradient.
+        pending = {}                                   # trunk node whose data gradient needs the head -> (event, tensors)
+        if side is not None:
+            ev0 = torch.cuda.Event()
+            ev0.record(main)                           # dloc / dconf are ready
+            with torch.cuda.stream(side):
+                side.wait_event(ev0)
+                for lvl in sorted(self.SIDE_HEADS, reverse=True):
+                    if lvl >= len(self.fm):
+                        continue
+                    tensors = head(lvl, self._ws_side)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    pending[self.fm[lvl][0] + 1] = (ev, tensors)
+        for lvl in range(len(self.fm)):
+            if side is not None and lvl in self.SIDE_HEADS:
+                continue
+            tensors = head(lvl, self._ws)
+            if on_ready:
+                on_ready(tensors)
+
+        def join(node):
+            ev, tensors = pending.pop(node)
+            main.wait_event(ev)
+            if on_ready:
+                on_ready(tensors)
+
         # trunk, last layer first
         for i in range(len(self.nodes) - 1, -1, -1):
             nd = self.nodes[i]
+            if i + 1 in pending:                       # a side head wrote gacts[i + 1]
+                join(i + 1)
             g_out = gacts[i + 1]
             assert written[i + 1]
             if nd["kind"] == "pool":
@@ -262,10 +328,14 @@ class SSDEngine:
                 on_ready([wt.index, bt.index])
             if i == 0:
                 continue                          # no gradient w.r.t. the image
+            if i in pending:                           # the data gradient below accumulates onto a side head's output
+                join(i)
             prev_is_relu_conv = self.nodes[i - 1]["kind"] == "conv"
             ops.conv2d_bwd_data(g_out, self.w_t[i], acts[i] if prev_is_relu_conv else None, acts[i].shape, nd["stride"],
                                 nd["pt"], nd["pl"], accumulate=written[i], out=gacts[i], ws=self._ws)
             written[i] = True
+        for node in list(pending):
+            join(node)
 
     # ---------------------------------------------------------------- optimizer
     def clip_scales(self, clip=0.01):

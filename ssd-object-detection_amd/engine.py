@@ -261,7 +261,12 @@ class SSDEngine:
 
     def backward(self, dloc, dconf, on_ready=None):
         """Gradients of all parameters into self.grad (flat fp32) from d(loss)/d(loc), d(loss)/d(conf).
-        on_ready([tensor indices]) is called right after the launches that complete those tensors' gradients."""
+        on_ready([tensor indices]) is called right after the launches that complete those tensors' gradients (on the
+        stream that runs them: an event recorded there covers them).
+
+        The data-gradient chain (the critical path) runs on the current stream, every weight gradient on the side
+        stream as soon as its input gradient exists: the split reductions and round tails of one overlap the MFMA
+        work of the other.  Each launch still sums in a fixed order, so results do not depend on the overlap."""
         B = dloc.shape[0]
         c = self._acts(B)
         acts, gacts = c["acts"], c["gacts"]
@@ -269,52 +274,36 @@ class SSDEngine:
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.overlap_heads else None
 
-        def head(lvl, ws):
-            ni, h, ch = self.fm[lvl]
+        def on_side(fn, tensors):
+            """Run fn (a weight-gradient launch) after everything enqueued so far on the main stream."""
+            if side is None:
+                fn(self._ws)
+                if on_ready:
+                    on_ready(tensors)
+                return
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                fn(self._ws_side)
+                if on_ready:
+                    on_ready(tensors)
+
+        # heads: weight gradients and their contribution to the feature-map gradients
+        for lvl, (ni, h, ch) in enumerate(self.fm):
             n = self.num_priors[lvl]
             packed = ops.head_grad_pack(dloc, dconf, h * h, n, self.classes, self.head_npad[lvl], self.level_off[lvl],
                                         out=c["packed"][lvl]).view(B, h, h, self.head_npad[lvl])
             wt, bt = self.head_params[lvl]
-            ops.conv2d_bwd_weight(acts[ni + 1], packed, wt.shape[0], 3, 1, 1, 1, dw=self.view(wt, self.grad),
-                                  dbias=self.view(bt, self.grad), ws=ws)
+            on_side(lambda ws, a=acts[ni + 1], p=packed, wt=wt, bt=bt: ops.conv2d_bwd_weight(
+                a, p, wt.shape[0], 3, 1, 1, 1, dw=self.view(wt, self.grad), dbias=self.view(bt, self.grad), ws=ws),
+                [wt.index, bt.index])
             ops.conv2d_bwd_data(packed, self.head_w_t[lvl], acts[ni + 1], acts[ni + 1].shape, 1, 1, 1,
-                                accumulate=False, out=gacts[ni + 1], ws=ws)
+                                accumulate=False, out=gacts[ni + 1], ws=self._ws)
             written[ni + 1] = True
-            return [wt.index, bt.index]
-
-        # heads: weight gradients and their contribution to the feature-map gradients.  The side-stream heads are joined
-        # (and reported ready) right before the first launch that accumulates into the same feature-map gradient.
-        pending = {}                                   # trunk node whose data gradient needs the head -> (event, tensors)
-        if side is not None:
-            ev0 = torch.cuda.Event()
-            ev0.record(main)                           # dloc / dconf are ready
-            with torch.cuda.stream(side):
-                side.wait_event(ev0)
-                for lvl in sorted(self.SIDE_HEADS, reverse=True):
-                    if lvl >= len(self.fm):
-                        continue
-                    tensors = head(lvl, self._ws_side)
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                    pending[self.fm[lvl][0] + 1] = (ev, tensors)
-        for lvl in range(len(self.fm)):
-            if side is not None and lvl in self.SIDE_HEADS:
-                continue
-            tensors = head(lvl, self._ws)
-            if on_ready:
-                on_ready(tensors)
-
-        def join(node):
-            ev, tensors = pending.pop(node)
-            main.wait_event(ev)
-            if on_ready:
-                on_ready(tensors)
-
         # trunk, last layer first
         for i in range(len(self.nodes) - 1, -1, -1):
             nd = self.nodes[i]
-            if i + 1 in pending:                       # a side head wrote gacts[i + 1]
-                join(i + 1)
             g_out = gacts[i + 1]
             assert written[i + 1]
             if nd["kind"] == "pool":
@@ -322,20 +311,17 @@ class SSDEngine:
                 written[i] = True
                 continue
             wt, bt = self.conv_params[i]
-            ops.conv2d_bwd_weight(acts[i], g_out, nd["cout"], nd["k"], nd["stride"], nd["pt"], nd["pl"],
-                                  dw=self.view(wt, self.grad), dbias=self.view(bt, self.grad), ws=self._ws)
-            if on_ready:
-                on_ready([wt.index, bt.index])
+            on_side(lambda ws, a=acts[i], go=g_out, nd=nd, wt=wt, bt=bt: ops.conv2d_bwd_weight(
+                a, go, nd["cout"], nd["k"], nd["stride"], nd["pt"], nd["pl"], dw=self.view(wt, self.grad),
+                dbias=self.view(bt, self.grad), ws=ws), [wt.index, bt.index])
             if i == 0:
                 continue                          # no gradient w.r.t. the image
-            if i in pending:                           # the data gradient below accumulates onto a side head's output
-                join(i)
             prev_is_relu_conv = self.nodes[i - 1]["kind"] == "conv"
             ops.conv2d_bwd_data(g_out, self.w_t[i], acts[i] if prev_is_relu_conv else None, acts[i].shape, nd["stride"],
                                 nd["pt"], nd["pl"], accumulate=written[i], out=gacts[i], ws=self._ws)
             written[i] = True
-        for node in list(pending):
-            join(node)
+        if side is not None:
+            main.wait_stream(side)
 
     # ---------------------------------------------------------------- optimizer
     def clip_scales(self, clip=0.01):

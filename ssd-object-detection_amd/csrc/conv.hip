@@ -1957,6 +1957,148 @@ __global__ __launch_bounds__(512) void k_conv3x3_wgrad_patch(const bf16_raw* __r
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the first layer (3x3 / stride 1 / pad 1, 8 input channels = 3 image channels + padding, <= 64
+// output channels): dW[co][tap][ch] = sum_px dY[px][co] * X[px + shift(tap)][ch], 72 columns.  The work is reading dY
+// once (HBM-bound); a workgroup walks 16x16-pixel blocks (dY tile 32 KB + an 18x18 x 16-byte halo patch, LDS-DMA,
+// double-buffered), wave w multiplies k-step w (32 pixels) of every block: 4 channel tiles x 5 column tiles (a column
+// tile = two taps x 8 channels) = 20 MFMAs; the eight partial sums are added in wave order at the end.
+constexpr int W0_DY = 256 * 128;                           // dY tile bytes
+constexpr int W0_PATCH = 6 * 1024;                         // 324 px x 16 B = 5184 B -> 6 DMA instructions
+constexpr int W0_BUF = W0_DY + W0_PATCH;
+
+__global__ __launch_bounds__(512) void k_conv0_wgrad(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ dy,
+                                                     float* __restrict__ slab_w, float* __restrict__ slab_b, ConvGeom g,
+                                                     int tiles_x, int tiles_y, int tiles_per_split, int cout) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int split = blockIdx.x;
+    const int ntiles = g.B * tiles_x * tiles_y;
+    const int t_begin = split * tiles_per_split, t_end = min(ntiles, t_begin + tiles_per_split);
+
+    auto issue_dma = [&](int t, int buf) {
+        int r = t;
+        const int tx = r % tiles_x; r /= tiles_x;
+        const int ty = r % tiles_y;
+        const int b = r / tiles_y;
+        const int y0 = ty * 16, x0 = tx * 16;
+        char* base = smem + buf * W0_BUF;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                       // dY: slot layout of k_conv3x3_wgrad_patch<16, 2>
+            const int i = wave + 8 * j;
+            const int kk = 8 * i + (lane >> 3), sl = lane & 7;
+            const int c16 = (((sl >> 1) ^ wp_key(kk)) << 1) | (sl & 1);
+            const int pg = kk >> 4;
+            const int y = y0 + 2 * (pg >> 1) + ((kk >> 3) & 1), xx = x0 + (pg & 1) * 8 + (kk & 7);
+            const int co = c16 * 8;
+            const bool ok = y < g.Ho && xx < g.Wo && co < g.N;
+            const bf16_raw* src = ok ? dy + ((unsigned)((b * g.Ho + y) * g.Wo + xx) * (unsigned)g.N + (unsigned)co)
+                                     : reinterpret_cast<const bf16_raw*>(g_zero16);
+            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(base + i * 1024), 16, 0, 0);
+        }
+        if (wave < 6) {                                     // patch: one 16-byte pixel per lane, row-major 18x18
+            const int pp = wave * 64 + lane;
+            const int py = pp / PATCH_W, px = pp - py * PATCH_W;
+            const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+            const bool ok = pp < PATCH_PIX && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+            const bf16_raw* src = ok ? x + (unsigned)((b * g.H + iy) * g.W + ix) * 8u : reinterpret_cast<const bf16_raw*>(g_zero16);
+            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(base + W0_DY + wave * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4_t acc[4][5];
+    f32x4_t accb[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        accb[a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 5; ++c) acc[a][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    bf16x8_t ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+
+    // this wave's k-step: block rows 2w, 2w+1.  MFMA k index <-> pixel as in k_conv3x3_wgrad_patch
+    const int gq = lane >> 4, li = lane & 15;
+    const int kk0 = (gq >> 1) * 8 + (gq & 1) * 4 + (li >> 2);
+    int abase[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) abase[a] = wave * 4096 + kk0 * 128 + ((a ^ wp_key(kk0)) << 5) + (li & 3) * 8;
+    // patch pixel of tap (0,0) for half 0: row 2w + (gq>>1), column 4 (gq&1) + (li>>2); column tile t: lanes with
+    // (li & 2) == 0 read tap 2t, the others tap 2t+1 (tap 9 does not exist: its columns are never stored)
+    const int p0 = (2 * wave + (gq >> 1)) * PATCH_W + (gq & 1) * 4 + (li >> 2);
+    int bbase[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        int tap = 2 * t + ((li >> 1) & 1);
+        if (tap > 8) tap = 8;
+        bbase[t] = W0_DY + (p0 + (tap / 3) * PATCH_W + tap % 3) * 16 + (li & 1) * 8;
+    }
+    typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
+    auto rd = [&](int addr) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + addr)); };
+
+    if (t_begin < t_end) issue_dma(t_begin, 0);
+    for (int t = t_begin; t < t_end; ++t) {
+        const int cur = (t - t_begin) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < t_end) issue_dma(t + 1, cur ^ 1);
+        const int boff = cur * W0_BUF;
+        bf16x8_t fa[4], fb[5];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) reinterpret_cast<s16x4_t*>(&fa[a])[half] = rd(boff + abase[a] + half * 2048);
+#pragma unroll
+            for (int c = 0; c < 5; ++c) reinterpret_cast<s16x4_t*>(&fb[c])[half] = rd(boff + bbase[c] + half * 8 * 16);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+            for (int c = 0; c < 5; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[c], acc[a][c], 0, 0, 0);
+            accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], ones, accb[a], 0, 0, 0);
+        }
+    }
+    // sum the eight waves' partial tiles in wave order (fixed order: reproducible), through LDS
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);            // [24 tiles][64 lanes][4]
+    for (int w = 0; w < 8; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    f32x4_t v;
+                    if (c < 5) v = acc[a][c < 5 ? c : 0]; else v = accb[a];
+                    f32x4_t* slot = reinterpret_cast<f32x4_t*>(red + ((a * 6 + c) * 64 + lane) * 4);
+                    if (w > 0) { const f32x4_t o = *slot; v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3]; }
+                    *slot = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // slab[split][co][72]; tile (a, c): D row = co a*16 + (lane>>4)*4 + j, column c*16 + (lane&15)
+    const int ktot = g.ldw;                                 // 72
+    for (int idx = tid; idx < 24 * 64; idx += 512) {
+        const int tile = idx >> 6, l = idx & 63;
+        const int a = tile / 6, c = tile - a * 6;
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(red + idx * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int co = a * 16 + (l >> 4) * 4 + j;
+            if (co >= g.N) continue;
+            if (c < 5) {
+                const int col = c * 16 + (l & 15);
+                if (col < ktot) slab_w[((long long)split * g.N + co) * ktot + col] = v[j];
+            } else if (slab_b != nullptr && (l & 15) == 0) {
+                slab_b[(long long)split * g.N + co] = v[j];
+            }
+        }
+    }
+}
+
 // dW[i] = sum_z slab[z][i] in fixed order; also the bias gradient.
 __global__ void k_wgrad_reduce(const float* __restrict__ slab, long long n, int nsplit, float* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1986,6 +2128,43 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce2(const float* __restrict__
         float s = 0.f;
         for (int z = 0; z < nsplit; ++z) s += slab_b[(long long)z * sb + i];
         db[i] = s;
+    }
+}
+
+// many splits, few outputs (first layer: 512 splits of 4.6 K values): 16 threads per float4 of the output, thread g adds
+// splits g, g+16, ... in order, then the 16 partial sums are added in order: fixed summation order, 16x the parallelism
+__global__ __launch_bounds__(256) void k_wgrad_reduce_wide(const float* __restrict__ slab_w, long long sw, long long nw,
+                                                          float* __restrict__ dw, const float* __restrict__ slab_b, long long sb,
+                                                          int nb, float* __restrict__ db, int nsplit, unsigned nbw) {
+    __shared__ float4 part[256];
+    const int o = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (blockIdx.x < nbw) {
+        const long long i = ((long long)blockIdx.x * 16 + o) * 4;
+        if (i < nw)
+            for (int z = grp; z < nsplit; z += 16) {
+                const float4 v = *reinterpret_cast<const float4*>(slab_w + (long long)z * sw + i);
+                s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+            }
+        part[threadIdx.x] = s4;
+        __syncthreads();
+        if (grp == 0 && i < nw) {
+            float4 t = part[o];
+            for (int k = 1; k < 16; ++k) { const float4 v = part[k * 16 + o]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+            *reinterpret_cast<float4*>(dw + i) = t;
+        }
+    } else {
+        const int i = (int)(blockIdx.x - nbw) * 16 + o;
+        float sacc = 0.f;
+        if (i < nb)
+            for (int z = grp; z < nsplit; z += 16) sacc += slab_b[(long long)z * sb + i];
+        part[threadIdx.x].x = sacc;
+        __syncthreads();
+        if (grp == 0 && i < nb) {
+            float t = part[o].x;
+            for (int k = 1; k < 16; ++k) t += part[k * 16 + o].x;
+            db[i] = t;
+        }
     }
 }
 
@@ -2123,7 +2302,7 @@ __global__ void k_head_grad_pack(const bf16_raw* __restrict__ dloc, const bf16_r
 struct Knob { const char* name; int value; bool init; };
 Knob g_knobs[] = {{"SSD_ABLATE", 0, false}, {"SSD_DGRAD_S2", 0, false}, {"SSD_CONV_VARIANT", 0, false}, {"SSD_CONV_PATCH", 0, false},
                   {"SSD_CONV_TILE", 0, false}, {"SSD_SPLITK", 0, false}, {"SSD_WGRAD_DMA", 0, false}, {"SSD_WGRAD_PATCH", 0, false},
-                  {"SSD_WGRAD_PATCH_SINGLE", 0, false}, {"SSD_WGRAD_PATCH_SHAPE", 0, false}, {"SSD_WGRAD_TILE", 0, false}, {"SSD_CONV_PATCH_FORM", 0, false}, {"SSD_CONV_PATCH_FLAT", 0, false}};
+                  {"SSD_WGRAD_PATCH_SINGLE", 0, false}, {"SSD_WGRAD_PATCH_SHAPE", 0, false}, {"SSD_WGRAD_TILE", 0, false}, {"SSD_CONV_PATCH_FORM", 0, false}, {"SSD_CONV_PATCH_FLAT", 0, false}, {"SSD_WGRAD_FIRST", 0, false}};
 Knob* find_knob(const char* name) {
     for (Knob& k : g_knobs) if (!strcmp(k.name, name)) return &k;
     return nullptr;
@@ -2382,6 +2561,24 @@ static int wgrad_patch_min_hw() {           // SSD_WGRAD_PATCH = smallest featur
     return knob("SSD_WGRAD_PATCH", 16);
 }
 
+// dW / dbias = sum over splits of the slabs, fixed order
+static void launch_wgrad_reduce(hipStream_t s, const float* slab_w, long long sw, long long nw, float* dw, const float* slab_b,
+                                long long sb, int nb, float* db, int ns) {
+    if (ns >= 32) {
+        const unsigned nbw = (unsigned)((nw / 4 + 15) / 16), nbb = db ? (unsigned)((nb + 15) / 16) : 0u;
+        hipLaunchKernelGGL(k_wgrad_reduce_wide, dim3(nbw + nbb), dim3(256), 0, s, slab_w, sw, nw, dw, slab_b, sb, nb, db, ns, nbw);
+    } else {
+        const unsigned nbw = (unsigned)((nw / 4 + 255) / 256), nbb = db ? (unsigned)((nb + 255) / 256) : 0u;
+        hipLaunchKernelGGL(k_wgrad_reduce2, dim3(nbw + nbb), dim3(256), 0, s, slab_w, sw, nw, dw, slab_b, sb, nb, db, ns, nbw);
+    }
+}
+
+// first layer (8 padded image channels): dedicated kernel, 512 pixel-block splits at most
+static bool wgrad_first_layer(int H, int W, int Ho, int Wo, int Cin, int Cout, int ldy, int ksize, int stride, int pad_t, int pad_l) {
+    return knob("SSD_WGRAD_FIRST", 1) && Cin == 8 && Cout <= 64 && ldy <= 64 && ksize == 3 && stride == 1 && pad_t == 1 && pad_l == 1 &&
+           H == Ho && W == Wo && H >= 16 && W >= 16;
+}
+
 static bool wgrad_use_patch(int H, int W, int Ho, int Wo, int Cin, int ksize, int stride, int pad_t, int pad_l) {
     const int mn = wgrad_patch_min_hw();
     return mn > 0 && ksize == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && H == Ho && W == Wo && Cin % 64 == 0 &&
@@ -2467,6 +2664,10 @@ size_t ssd_conv2d_bwd_weight_workspace_bytes(int B, int Ho, int Wo, int Cin, int
     const int tiles = (int)(((ktot + bnc - 1) / bnc) * ((Cout + bmo - 1) / bmo));
     const int ns = wgrad_splits((long long)B * Ho * Wo, tiles);
     size_t gen = (size_t)ns * ((size_t)ldy * ktot + ldy) * sizeof(float);
+    if (Cin == 8 && Cout <= 64 && ldy <= 64 && ksize == 3) {  // first-layer kernel: up to 512 splits
+        const size_t first = (size_t)512 * ((size_t)ldy * ktot + ldy) * sizeof(float);
+        if (first > gen) gen = first;
+    }
     if (Cout > 128 && ktot >= 256) {                          // the 256x256 GEMM kernel may serve the call
         const int t2 = (int)(((ktot + 255) / 256) * ((Cout + 255) / 256));
         const int ns2 = wgrad_tile_splits((long long)B * Ho * Wo, t2, (long long)ldy * ktot);
@@ -2484,6 +2685,27 @@ int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias
     if (!ws || ws_bytes < ssd_conv2d_bwd_weight_workspace_bytes(B, Ho, Wo, Cin, Cout, ldy, ksize)) return SSD_ERR_WORKSPACE;
     ConvGeom g = make_geom(B, H, W, Cin, Ho, Wo, ldy, ksize, ksize, stride, 1, pad_t, pad_l);
     const long long ktot = g.ldw;
+    if (wgrad_first_layer(H, W, Ho, Wo, Cin, Cout, ldy, ksize, stride, pad_t, pad_l)) {
+        const int tx = (Wo + 15) / 16, ty = (Ho + 15) / 16, ntiles = B * tx * ty;
+        const int ns = ntiles < 512 ? ntiles : 512;
+        const int tps = (ntiles + ns - 1) / ns;
+        float* slab_w = static_cast<float*>(ws);
+        float* slab_b = slab_w + (size_t)ns * ldy * ktot;
+        hipStream_t s = (hipStream_t)stream;
+        static bool set = false;
+        if (!set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv0_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    2 * W0_BUF) != hipSuccess) return SSD_ERR_LAUNCH;
+            set = true;
+        }
+        hipLaunchKernelGGL(k_conv0_wgrad, dim3((unsigned)((ntiles + tps - 1) / tps)), dim3(512), 2 * W0_BUF, s,
+                           static_cast<const bf16_raw*>(x), static_cast<const bf16_raw*>(dy), slab_w, dbias ? slab_b : nullptr, g,
+                           tx, ty, tps, Cout);
+        if (hipGetLastError() != hipSuccess) return SSD_ERR_LAUNCH;
+        const int nsr = (ntiles + tps - 1) / tps;
+        launch_wgrad_reduce(s, slab_w, (long long)ldy * ktot, (long long)Cout * ktot, dw, slab_b, (long long)ldy, Cout, dbias, nsr);
+        return ssd_launch_status();
+    }
     if (wgrad_use_patch(H, W, Ho, Wo, Cin, ksize, stride, pad_t, pad_l)) {
         int tx, ty, tps, ns;
         wgrad_patch_plan(B, Ho, Wo, Cin, Cout, &tx, &ty, &tps, &ns);
@@ -2513,10 +2735,7 @@ int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias
         else SSD_LAUNCH_WP(16, 2);
 #undef SSD_LAUNCH_WP
         if (hipGetLastError() != hipSuccess) return SSD_ERR_LAUNCH;
-        const long long nw = (long long)Cout * ktot;            // multiple of 4 (ktot = 9*Cin, Cin % 8 == 0)
-        const unsigned nbw = (unsigned)((nw / 4 + 255) / 256), nbb = dbias ? (unsigned)((Cout + 255) / 256) : 0u;
-        hipLaunchKernelGGL(k_wgrad_reduce2, dim3(nbw + nbb), dim3(256), 0, s, slab_w, (long long)ldy * ktot, nw, dw, slab_b,
-                           (long long)ldy, Cout, dbias, ns, nbw);
+        launch_wgrad_reduce(s, slab_w, (long long)ldy * ktot, (long long)Cout * ktot, dw, slab_b, (long long)ldy, Cout, dbias, ns);
         return ssd_launch_status();
     }
     if (wgrad_use_tile(g.M, Cout, ldy, ktot, (long long)B * H * W * Cin)) {
@@ -2537,10 +2756,7 @@ int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias
                            static_cast<const bf16_raw*>(x), static_cast<const bf16_raw*>(dy), slab_w, dbias ? slab_b : nullptr, g,
                            mps, ns, Cout);
         if (hipGetLastError() != hipSuccess) return SSD_ERR_LAUNCH;
-        const long long nw = (long long)Cout * ktot;
-        const unsigned nbw = (unsigned)((nw / 4 + 255) / 256), nbb = dbias ? (unsigned)((Cout + 255) / 256) : 0u;
-        hipLaunchKernelGGL(k_wgrad_reduce2, dim3(nbw + nbb), dim3(256), 0, s, slab_w, (long long)ldy * ktot, nw, dw, slab_b,
-                           (long long)ldy, Cout, dbias, ns, nbw);
+        launch_wgrad_reduce(s, slab_w, (long long)ldy * ktot, (long long)Cout * ktot, dw, slab_b, (long long)ldy, Cout, dbias, ns);
         return ssd_launch_status();
     }
     int bmo, bnc;
@@ -2592,10 +2808,7 @@ int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias
 #undef SSD_LAUNCH_WG
     }
     if (hipGetLastError() != hipSuccess) return SSD_ERR_LAUNCH;
-    const long long nw = (long long)Cout * ktot;             // rows >= Cout of the slab are padding channels; nw % 4 == 0
-    const unsigned nbw = (unsigned)((nw / 4 + 255) / 256), nbb = dbias ? (unsigned)((Cout + 255) / 256) : 0u;
-    hipLaunchKernelGGL(k_wgrad_reduce2, dim3(nbw + nbb), dim3(256), 0, s, slab_w, (long long)ldy * ktot, nw, dw, slab_b,
-                       (long long)ldy, Cout, dbias, ns, nbw);
+    launch_wgrad_reduce(s, slab_w, (long long)ldy * ktot, (long long)Cout * ktot, dw, slab_b, (long long)ldy, Cout, dbias, ns);
     return ssd_launch_status();
 }
 

@@ -1193,6 +1193,129 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 
 // ------------------------------------------------------------------------------------------------
+// First layer, forward: 3x3 / stride 1 / pad 1, 8 input channels (3 image channels + padding), 64 output channels,
+// bias + ReLU.  33 us of MFMA work against 830 MB of traffic: the kernel is organised around the stores.  A workgroup
+// owns a 16x16 block: the 18x18 halo patch is 5 KB (one 16-byte pixel per DMA lane), the whole [64][72] weight matrix
+// lives in registers as MFMA A fragments (k = 4 taps x 8 channels per MFMA, 3 MFMAs cover the 9 taps), every wave
+// computes two 16-pixel rows and turns each [16 px][64 ch] result through its private 2 KB of LDS so that it leaves as
+// two fully coalesced 1 KiB stores (16 consecutive NHWC pixels are contiguous).
+__global__ __launch_bounds__(512) void k_conv0_fwd(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ w,
+                                                   const float* __restrict__ bias, bf16_raw* __restrict__ out, ConvGeom g,
+                                                   int relu, int tiles_x, int tiles_y) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 6 * 1024 + 8 * 2048];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nblocks = g.B * tiles_x * tiles_y;
+    // persistent: blocks blockIdx.x, + gridDim.x, ...; the next block's patch is in flight while this one is computed
+    auto issue_patch = [&](int t, int buf) {
+        if (wave < 6) {                                     // one pixel per lane, row-major 18x18
+            int r = t;
+            const int tx = r % tiles_x; r /= tiles_x;
+            const int ty = r % tiles_y;
+            const int b = r / tiles_y;
+            const int pp = wave * 64 + lane;
+            const int py = pp / PATCH_W, px = pp - py * PATCH_W;
+            const int iy = ty * 16 - 1 + py, ix = tx * 16 - 1 + px;
+            const bool ok = pp < PATCH_PIX && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+            const bf16_raw* src = ok ? x + (unsigned)((b * g.H + iy) * g.W + ix) * 8u : reinterpret_cast<const bf16_raw*>(g_zero16);
+            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(smem + buf * 6144 + wave * 1024), 16, 0, 0);
+        }
+    };
+    if ((int)blockIdx.x < nblocks) issue_patch(blockIdx.x, 0);
+    // weights as A fragments: lane (row = lane & 15, k chunk fk = lane >> 4) of tile c, k-step ks holds
+    // w[c*16 + row][tap = 4 ks + fk][0..7]
+    const int frow = lane & 15, fk = lane >> 4;
+    bf16x8_t fw[4][3];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const int tap = 4 * ks + fk, co = c * 16 + frow;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (tap < 9 && co < g.N) v = *reinterpret_cast<const uint4*>(w + (unsigned)co * 72u + (unsigned)tap * 8u);
+            fw[c][ks] = *reinterpret_cast<const bf16x8_t*>(&v);
+        }
+    float b4[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int n = c * 16 + fk * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b4[c][j] = (bias && n + j < g.N) ? bias[n + j] : 0.f;
+    }
+    // pixel fragment of k-step ks: lane (pixel = lane & 15, fk) reads the patch pixel shifted by tap 4 ks + fk
+    int toff[3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+        int tap = 4 * ks + fk;
+        if (tap > 8) tap = 8;                               // weights of the missing taps are zero
+        toff[ks] = ((tap / 3) * PATCH_W + tap % 3 + frow) * 16;
+    }
+    char* stage = smem + 2 * 6144 + wave * 2048;
+    int it = 0, prev_st = 0;
+    for (int t = blockIdx.x; t < nblocks; t += gridDim.x, ++it) {
+        const int cur = it & 1;
+        // the patch DMA of this block is older than the stores this wave issued since: leave those in flight.  prev_st
+        // counts only the store instructions that had at least one active lane (wave-uniform), i.e. a lower bound
+        if (prev_st >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (prev_st == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (prev_st == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (prev_st == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + (int)gridDim.x < nblocks) issue_patch(t + gridDim.x, cur ^ 1);
+        int r = t;
+        const int tx = r % tiles_x; r /= tiles_x;
+        const int ty = r % tiles_y;
+        const int b = r / tiles_y;
+        const int y0 = ty * 16, x0 = tx * 16;
+        const char* patch = smem + cur * 6144;
+        prev_st = 0;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) prev_st += (y0 + 2 * wave + p < g.Ho && x0 + 8 * h < g.Wo) ? 1 : 0;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int row = 2 * wave + p;                   // block row of this pixel tile
+            bf16x8_t fx[3];
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) fx[ks] = *reinterpret_cast<const bf16x8_t*>(patch + row * (PATCH_W * 16) + toff[ks]);
+            f32x4_t acc[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[c][ks], fx[ks], acc[c], 0, 0, 0);
+            }
+            // lane holds channels c*16 + fk*4 + {0..3} of pixel frow: bias, ReLU, pack, into the wave's staging tile
+            // [16 px][128 B] with the 16-byte chunk index XORed by (px & 7)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float v[4] = {acc[c][0] + b4[c][0], acc[c][1] + b4[c][1], acc[c][2] + b4[c][2], acc[c][3] + b4[c][3]};
+                if (relu) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                }
+                *reinterpret_cast<uint2*>(stage + frow * 128 + (((c * 2 + (fk >> 1)) ^ (frow & 7)) << 4) + (fk & 1) * 8) =
+                    make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave wrote it: no barrier needed
+            const int y = y0 + row;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int idx = h * 64 + lane;
+                const int px = idx >> 3, ch = idx & 7;
+                const uint4 v = *reinterpret_cast<const uint4*>(stage + px * 128 + ((ch ^ (px & 7)) << 4));
+                const int xx = x0 + px;
+                if (y < g.Ho && xx < g.Wo)          // N == 64 (host check): every chunk of the pixel is stored
+                    *reinterpret_cast<uint4*>(out + ((unsigned)((b * g.Ho + y) * g.Wo + xx) * 64u + (unsigned)(ch * 8))) = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging tile is reused by the second row
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Weight gradient.  grid (col tiles, co tiles, splits).  Per step 64 pixels.
 constexpr int WG_LD = 288;                   // LDS row stride (bytes) of a [pixel][128 ch] tile: 256 + 32 pad
 
@@ -2302,7 +2425,7 @@ __global__ void k_head_grad_pack(const bf16_raw* __restrict__ dloc, const bf16_r
 struct Knob { const char* name; int value; bool init; };
 Knob g_knobs[] = {{"SSD_ABLATE", 0, false}, {"SSD_DGRAD_S2", 0, false}, {"SSD_CONV_VARIANT", 0, false}, {"SSD_CONV_PATCH", 0, false},
                   {"SSD_CONV_TILE", 0, false}, {"SSD_SPLITK", 0, false}, {"SSD_WGRAD_DMA", 0, false}, {"SSD_WGRAD_PATCH", 0, false},
-                  {"SSD_WGRAD_PATCH_SINGLE", 0, false}, {"SSD_WGRAD_PATCH_SHAPE", 0, false}, {"SSD_WGRAD_TILE", 0, false}, {"SSD_CONV_PATCH_FORM", 0, false}, {"SSD_CONV_PATCH_FLAT", 0, false}, {"SSD_WGRAD_FIRST", 0, false}};
+                  {"SSD_WGRAD_PATCH_SINGLE", 0, false}, {"SSD_WGRAD_PATCH_SHAPE", 0, false}, {"SSD_WGRAD_TILE", 0, false}, {"SSD_CONV_PATCH_FORM", 0, false}, {"SSD_CONV_PATCH_FLAT", 0, false}, {"SSD_WGRAD_FIRST", 0, false}, {"SSD_CONV_FIRST", 0, false}};
 Knob* find_knob(const char* name) {
     for (Knob& k : g_knobs) if (!strcmp(k.name, name)) return &k;
     return nullptr;
@@ -2522,6 +2645,14 @@ int ssd_conv2d_fwd(const void* x, const void* w, const float* bias, void* y, int
                    void* stream) {
     if (!x || !w || !y || !geom_ok(B, H, W, Cin, Ho, Wo, Cout, ksize) || stride <= 0) return SSD_ERR_VALUE;
     const ConvGeom g = make_geom(B, H, W, Cin, Ho, Wo, Cout, ksize, ksize, stride, 1, pad_t, pad_l);
+    if (knob("SSD_CONV_FIRST", 1) && Cin == 8 && Cout == 64 && ksize == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && H == Ho &&
+        W == Wo && H >= 16 && W >= 16) {                     // the image layer
+        const int tx = (Wo + 15) / 16, ty = (Ho + 15) / 16;
+        hipLaunchKernelGGL(k_conv0_fwd, dim3((unsigned)(B * tx * ty < 768 ? B * tx * ty : 768)), dim3(512), 0, (hipStream_t)stream,
+                           static_cast<const bf16_raw*>(x), static_cast<const bf16_raw*>(w), bias, static_cast<bf16_raw*>(y), g, relu,
+                           tx, ty);
+        return ssd_launch_status();
+    }
     Epilogue ep = {};
     ep.bias = bias; ep.relu = relu; ep.out = static_cast<bf16_raw*>(y); ep.ldo = Cout;
     return launch_igemm<EPI_FWD>(x, w, g, ep, (hipStream_t)stream, ws, ws_bytes);

@@ -112,6 +112,29 @@ def test_conv_fwd_bwd(ops, case):
     assert torch.equal(dw, dw2)
 
 
+def test_first_layer_kernels_full_size(ops):
+    """The dedicated image-layer kernels (8 padded channels -> 64) at the real map size: more blocks than persistent
+    workgroups (several iterations per workgroup), ragged right/bottom blocks, forward and weight gradient."""
+    B, H, Cin, Cout = 4, 300, 8, 64
+    g = torch.Generator().manual_seed(21)
+    x = torch.zeros((B, H, H, Cin)).bfloat16()
+    x[..., :3] = torch.randn((B, H, H, 3), generator=g).bfloat16()
+    w = (torch.randn((Cout, 3, 3, Cin), generator=g) / np.sqrt(27)).bfloat16()
+    bias = torch.randn((Cout,), generator=g) * 0.1
+    dy = torch.randn((B, H, H, Cout), generator=g).bfloat16()
+    y = ops.conv2d_fwd(x.cuda(), w.cuda(), bias.cuda(), 1, 1, 1, H, H, True).float().cpu()
+    wr = w.float().requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    yr = ref_conv(x.float(), wr, br, 3, 1, 1, 1, H, H, False)
+    assert (y - yr.detach().relu()).abs().max().item() <= 2 ** -7 * max(1.0, yr.abs().max().item())
+    yr.backward(dy.float())
+    dw, db = ops.conv2d_bwd_weight(x.cuda(), dy.cuda(), Cout, 3, 1, 1, 1)
+    assert (dw.cpu() - wr.grad).abs().max().item() <= 2e-3 * max(1.0, wr.grad.abs().max().item())
+    assert (db.cpu() - br.grad).abs().max().item() <= 2e-3 * max(1.0, br.grad.abs().max().item())
+    dw2, _ = ops.conv2d_bwd_weight(x.cuda(), dy.cuda(), Cout, 3, 1, 1, 1)
+    assert torch.equal(dw, dw2)
+
+
 @pytest.mark.parametrize("case", [(2, 30, 30, 64, 64), (3, 17, 23, 128, 96), (1, 38, 38, 64, 136)])
 def test_patch_strip_blocks_forced(ops, case):
     """Strip blocks (SSD_CONV_PATCH_FLAT=2 forces them wherever the map is narrow enough) give the same forward and

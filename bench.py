@@ -140,7 +140,7 @@ def main():
         conv_flops = FLOP_TRAIN_PER_IMAGE * B
         conv_time = t_fwd + t_bwd
         result["roofline"] = {
-            "bound": "mfma", "kernel": "k_conv_igemm + k_conv_wgrad (all conv launches of one step)",
+            "bound": "mfma", "kernel": "all convolution launches of one step (k_conv3x3_patch32, k_conv3x3_wgrad_patch, k_conv_igemm_*, k_conv_wgrad_*, k_conv0_*)",
             "achieved": round(conv_flops / conv_time / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(conv_flops / conv_time / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None,
             "fwd_ms": round(t_fwd * 1e3, 3), "bwd_ms": round(t_bwd * 1e3, 3),

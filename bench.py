@@ -139,10 +139,17 @@ def main():
         t_bwd = timed(lambda: eng.backward(dloc, dconf), 3)
         conv_flops = FLOP_TRAIN_PER_IMAGE * B
         conv_time = t_fwd + t_bwd
+        # memory-side traffic of the convolution launches of one step, from rocprofv3 PMC passes (separate --pmc FETCH_SIZE /
+        # WRITE_SIZE runs of tools_dev/time_step.py, summed by tools_dev/pmc_conv_traffic.py; FETCH_SIZE doubled: gfx950
+        # tallies 128-byte requests at 64 B, MI355X_MICROARCH.md "HBM").  Only valid for the batch it was collected at.
+        conv_traffic = None
+        conv_pmc = os.path.join(ROOT, "profiles", "r01_conv_pmc.json")
+        if B == 64 and os.path.exists(conv_pmc):
+            conv_traffic = int(json.load(open(conv_pmc))["conv_hbm_bytes_per_step"])
         result["roofline"] = {
             "bound": "mfma", "kernel": "all convolution launches of one step (k_conv3x3_patch32, k_conv3x3_wgrad_patch, k_conv_igemm_*, k_conv_wgrad_*, k_conv0_*)",
             "achieved": round(conv_flops / conv_time / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(conv_flops / conv_time / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "frac": round(conv_flops / conv_time / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": conv_traffic,
             "fwd_ms": round(t_fwd * 1e3, 3), "bwd_ms": round(t_bwd * 1e3, 3),
             "fwd_tflops": round(FLOP_FWD_PER_IMAGE * B / t_fwd / 1e12, 2)}
         # anchor matching: graph-replayed so that host launch overhead is not in the number

@@ -1046,7 +1046,7 @@ constexpr int P32_PATCH = 32 * 1024;                       // 324 px x 96 B = 31
 
 template <int BN, int EPI, bool FLAT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_conv3x3_patch32(
-    const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ w, ConvGeom g, Epilogue ep, int tiles_x, int tiles_y) {
+    const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ w, ConvGeom g, Epilogue ep, int tiles_x, int tiles_y, int nblocks) {
     constexpr int CT = BN / 32;
     constexpr int PT = 4;
     constexpr int WBYTES = BN * 64;                          // weight slice of one tap
@@ -1062,15 +1062,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // on either side) and images separated by ONE zero row; a block is 256 consecutive positions, its patch those plus
     // Q + 1 on either side, tap (kh,kw) is position + kh*Q + kw.  Pad positions are computed and dropped: 7 % of the
     // work at 38x38 and 14 % at 19x19, where 16x16 blocks would waste 37 % and 65 %.
-    const int n0 = blockIdx.y * BN;
+    // XCD-aware order (workgroup L runs on XCD L % 8): the channel tiles of one pixel block are consecutive on ONE
+    // XCD, so the block's patch is fetched into that L2 once
+    const int ntn = (g.N + BN - 1) / BN;
+    const int kx = blockIdx.x >> 3;
+    const int pblock = (kx / ntn) * 8 + (blockIdx.x & 7);
+    if (pblock >= nblocks) return;
+    const int n0 = (kx % ntn) * BN;
     constexpr bool flat = FLAT;
     const int Q = FLAT ? g.W + 2 : PATCH_W;
     const int img = (g.H + 1) * Q;                          // flat positions per image
     int b = 0, y0 = 0, x0 = 0, f0 = 0;
     if constexpr (FLAT) {
-        f0 = blockIdx.x * 256;
+        f0 = pblock * 256;
     } else {
-        int t = blockIdx.x;
+        int t = pblock;
         const int tx = t % tiles_x; t /= tiles_x;
         const int ty = t % tiles_y;
         b = t / tiles_y;
@@ -1151,8 +1157,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int tap = 0; tap < 9; ++tap) {
             const int wb = ((chunk + tap) & 1) * WBYTES;    // step s = 9 chunk + tap: s & 1 == (chunk + tap) & 1
             // this step's weight slice has landed (the patch prefetch issued after it at tap 0 may still be in flight)
-            if (tap == 1 && next_chunk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // ... and this wave's LDS reads of the previous step are retired (lgkmcnt) BEFORE the barrier: the weight
+            // buffer they came from is re-staged right after it (a read merely issued before the barrier can still be
+            // queued in the LDS when a fast L2-hit DMA of another wave lands)
+            if (tap == 1 && next_chunk) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (tap < 8) dma_w(chunk, tap + 1, ((chunk + tap + 1) & 1));
             else if (next_chunk) dma_w(chunk + 1, 0, ((chunk + tap + 1) & 1));
@@ -1884,7 +1893,7 @@ template <int BH, int BW8>
 __global__ __launch_bounds__(512) void k_conv3x3_wgrad_patch(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ dy,
                                                              float* __restrict__ slab_w, float* __restrict__ slab_b,
                                                              ConvGeom g, int tiles_x, int tiles_y, int tiles_per_split,
-                                                             int nsplit, int cout, int single_buf) {
+                                                             int nsplit, int cout, int single_buf, int xg) {
     // g: source = x (B,H,W,C), destination = dy (Ho=H, Wo=W, N = ldy)
     using G = WpGeom<BH, BW8>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1894,8 +1903,15 @@ __global__ __launch_bounds__(512) void k_conv3x3_wgrad_patch(const bf16_raw* __r
     // tile (w>>1) x all nine taps = 18 accumulator tiles
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ap = wave & 1, ct = wave >> 1;
+    // work units (split, co tile, ci chunk), chunk fastest.  XCD-aware order (workgroup L runs on XCD L % 8): `xg`
+    // consecutive units -- the channel groups that walk the SAME pixel blocks -- sit on one XCD, so that a dY tile /
+    // X patch is fetched into that L2 once instead of once per group (xg from the host: a divisor of the unit count
+    // per split, or a multiple of it, that still leaves every XCD with work)
     const int nchunk = g.C >> 6, cotiles = (cout + 63) >> 6;
-    int id = blockIdx.x;
+    const int nunits = nchunk * cotiles * nsplit;
+    const int j = blockIdx.x >> 3;
+    int id = ((j / xg) * 8 + (blockIdx.x & 7)) * xg + j % xg;
+    if (id >= nunits) return;
     const int chunk = id % nchunk; id /= nchunk;
     const int cot = id % cotiles;
     const int split = id / cotiles;
@@ -2425,7 +2441,7 @@ __global__ void k_head_grad_pack(const bf16_raw* __restrict__ dloc, const bf16_r
 struct Knob { const char* name; int value; bool init; };
 Knob g_knobs[] = {{"SSD_ABLATE", 0, false}, {"SSD_DGRAD_S2", 0, false}, {"SSD_CONV_VARIANT", 0, false}, {"SSD_CONV_PATCH", 0, false},
                   {"SSD_CONV_TILE", 0, false}, {"SSD_SPLITK", 0, false}, {"SSD_WGRAD_DMA", 0, false}, {"SSD_WGRAD_PATCH", 0, false},
-                  {"SSD_WGRAD_PATCH_SINGLE", 0, false}, {"SSD_WGRAD_PATCH_SHAPE", 0, false}, {"SSD_WGRAD_TILE", 0, false}, {"SSD_CONV_PATCH_FORM", 0, false}, {"SSD_CONV_PATCH_FLAT", 0, false}, {"SSD_WGRAD_FIRST", 0, false}, {"SSD_CONV_FIRST", 0, false}};
+                  {"SSD_WGRAD_PATCH_SINGLE", 0, false}, {"SSD_WGRAD_PATCH_SHAPE", 0, false}, {"SSD_WGRAD_TILE", 0, false}, {"SSD_CONV_PATCH_FORM", 0, false}, {"SSD_CONV_PATCH_FLAT", 0, false}, {"SSD_WGRAD_FIRST", 0, false}, {"SSD_CONV_FIRST", 0, false}, {"SSD_WGRAD_PATCH_XCD", 0, false}};
 Knob* find_knob(const char* name) {
     for (Knob& k : g_knobs) if (!strcmp(k.name, name)) return &k;
     return nullptr;
@@ -2497,7 +2513,8 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
                         return SSD_ERR_LAUNCH;                                                                      \
                     set_ = true;                                                                                    \
                 }                                                                                                   \
-                hipLaunchKernelGGL(kern_, dim3(gxx, (unsigned)((g.N + BN_ - 1) / BN_)), dim3(512), lds_, s, xp, wp, g, ep, tiles_x, tiles_y); \
+                const unsigned ntn_ = (unsigned)((g.N + BN_ - 1) / BN_);                                            \
+                hipLaunchKernelGGL(kern_, dim3(8 * ntn_ * ((gxx + 7) / 8)), dim3(512), lds_, s, xp, wp, g, ep, tiles_x, tiles_y, (int)gxx); \
             } while (0)
             if (g.N <= 64) { if (flat) SSD_LAUNCH_P32(64, true); else SSD_LAUNCH_P32(64, false); }
             else { if (flat) SSD_LAUNCH_P32(128, true); else SSD_LAUNCH_P32(128, false); }
@@ -2844,7 +2861,12 @@ int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias
         float* slab_b = slab_w + (size_t)ns * ldy * ktot;
         hipStream_t s = (hipStream_t)stream;
         const int single = knob("SSD_WGRAD_PATCH_SINGLE", 0);
-        const unsigned grid = (unsigned)((Cin / 64) * ((Cout + 63) / 64) * ns);
+        const int groups = (Cin / 64) * ((Cout + 63) / 64), nunits = groups * ns;
+        // units per XCD group: all channel groups of a split when that leaves >= 16 groups of units, else halve
+        int xg = groups;
+        while (xg > 1 && nunits / xg < 16 && xg % 2 == 0) xg /= 2;
+        if (!knob("SSD_WGRAD_PATCH_XCD", 1)) xg = 1;
+        const unsigned grid = (unsigned)(8 * xg * ((nunits + 8 * xg - 1) / (8 * xg)));
         int bh, bw;
         const int shape = wgrad_patch_shape(Ho, Wo, &bh, &bw);
 #define SSD_LAUNCH_WP(BH_, BW8_)                                                                                    \
@@ -2859,7 +2881,7 @@ int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias
             }                                                                                                       \
             hipLaunchKernelGGL(kern_, dim3(grid), dim3(512), (size_t)(single ? 1 : 2) * G_::BUF, s,                  \
                                static_cast<const bf16_raw*>(x), static_cast<const bf16_raw*>(dy), slab_w,          \
-                               dbias ? slab_b : nullptr, g, tx, ty, tps, ns, Cout, single);                         \
+                               dbias ? slab_b : nullptr, g, tx, ty, tps, ns, Cout, single, xg);                     \
         } while (0)
         if (shape == 1) SSD_LAUNCH_WP(6, 5);
         else if (shape == 2) SSD_LAUNCH_WP(10, 3);

@@ -77,6 +77,36 @@ def test_forward_backward_vs_oracle(engine):
     print("worst relative gradient error", worst)
 
 
+def test_two_stream_schedule_is_bitwise_neutral(engine):
+    """The side-stream schedule (weight gradients and the large heads next to the main chain) must not change a single
+    bit: every launch sums in a fixed order and the only shared accumulation target is ordered by events.  Run at a
+    batch where kernels of both streams really share the GPU (this is what exposed a missing LDS-read wait once)."""
+    import ssd_object_detection_amd.ops as ops
+    B = 8
+    g = torch.Generator().manual_seed(17)
+    x = ops.image_prep(torch.rand((B, 300, 300, 3), generator=g).cuda())
+    dloc = (torch.randn((B, 8732, 4), generator=g) * 1e-3).bfloat16().cuda()
+    dconf = (torch.randn((B, 8732, 81), generator=g) * 1e-3).bfloat16().cuda()
+
+    def run(overlap):
+        engine.overlap_heads = overlap
+        engine.grad.zero_()
+        loc, conf = engine.forward(x)
+        engine.backward(dloc, dconf)
+        torch.cuda.synchronize()
+        return engine.grad.clone(), loc.clone(), conf.clone()
+
+    saved = engine.overlap_heads
+    try:
+        ref = run(False)
+        for _ in range(4):
+            got = run(True)
+            assert torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2])
+            assert torch.equal(got[0], ref[0])
+    finally:
+        engine.overlap_heads = saved
+
+
 def test_optimizer_vs_oracle(engine):
     """clip_by_norm per tensor + Adam on the flat buffer vs the numpy oracle (Keras formulas)."""
     g = torch.Generator().manual_seed(2)

@@ -194,6 +194,12 @@ int ssd_maxpool2x2_fwd(const void* x, void* y, int B, int H, int W, int C, int H
 /* pooling backward fused with the ReLU backward of the layer that produced x */
 int ssd_maxpool2x2_bwd(const void* x, const void* y, const void* dy, void* dx, int B, int H, int W, int C, int Ho,
                        int Wo, void* stream);
+/* The same pooling with a recorded winner (training): `code` u32 [B*Ho*Wo*C/8] receives one 4-bit code per pooled
+ * element (window position 2*dy+dx of the first maximum, 4 = maximum <= 0: no gradient through the ReLU in front);
+ * the backward pass then reads only dy and the codes.  Results are identical to ssd_maxpool2x2_fwd / _bwd. */
+int ssd_maxpool2x2_fwd_argmax(const void* x, void* y, void* code, int B, int H, int W, int C, int Ho, int Wo, void* stream);
+int ssd_maxpool2x2_bwd_argmax(const void* code, const void* dy, void* dx, int B, int H, int W, int C, int Ho, int Wo,
+                              void* stream);
 /* dloc[B,A,4], dconf[B,A,classes] (bf16) -> one level's padded NHWC head gradient [B, hw, npad] */
 int ssd_head_grad_pack(const void* dloc, const void* dconf, void* out, int B, int hw, int per_cell, int classes,
                        int npad, int anchors_total, int level_off, void* stream);

@@ -45,6 +45,8 @@ _SIGNATURES = {
     "ssd_image_prep": (ctypes.c_int, [VP, VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, VP]),
     "ssd_maxpool2x2_fwd": (ctypes.c_int, [VP, VP] + [ctypes.c_int] * 6 + [VP]),
     "ssd_maxpool2x2_bwd": (ctypes.c_int, [VP, VP, VP, VP] + [ctypes.c_int] * 6 + [VP]),
+    "ssd_maxpool2x2_fwd_argmax": (ctypes.c_int, [VP, VP, VP] + [ctypes.c_int] * 6 + [VP]),
+    "ssd_maxpool2x2_bwd_argmax": (ctypes.c_int, [VP, VP, VP] + [ctypes.c_int] * 6 + [VP]),
     "ssd_head_grad_pack": (ctypes.c_int, [VP, VP, VP] + [ctypes.c_int] * 7 + [VP]),
     "ssd_opt_block_elems": (ctypes.c_int, []),
     "ssd_grad_clip_scales": (ctypes.c_int, [VP, ctypes.c_longlong, VP, ctypes.c_int, ctypes.c_float, VP, VP, VP, VP]),

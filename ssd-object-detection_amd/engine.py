@@ -203,7 +203,9 @@ class SSDEngine:
             conf = torch.empty((B, self.A, self.classes), dtype=torch.bfloat16, device=dev)
             packed = [torch.empty((B, h * h, npad), dtype=torch.bfloat16, device=dev)
                       for (_, h, _), npad in zip(self.fm, self.head_npad)]
-            c = dict(acts=acts, gacts=gacts, loc=loc, conf=conf, packed=packed)
+            pool_code = {i: torch.empty((B, nd["hout"], nd["hout"], nd["cout"] // 8), dtype=torch.int32, device=dev)
+                         for i, nd in enumerate(self.nodes) if nd["kind"] == "pool"}
+            c = dict(acts=acts, gacts=gacts, loc=loc, conf=conf, packed=packed, pool_code=pool_code)
             self._act_cache = {B: c}              # keep one batch size resident
         return c
 
@@ -242,9 +244,8 @@ class SSDEngine:
                 ops.conv2d_fwd(acts[i], self.view(wt, self.param_bf16), self.view(bt, self.param), nd["stride"],
                                nd["pt"], nd["pl"], nd["hout"], nd["hout"], True, out=acts[i + 1], ws=self._ws)
             else:
-                L = self.L
-                _lib.check(L.ssd_maxpool2x2_fwd(ops._ptr(acts[i]), ops._ptr(acts[i + 1]), B, nd["hin"], nd["hin"],
-                                                nd["cin"], nd["hout"], nd["hout"], ops._stream()))
+                ops.maxpool2x2_fwd_argmax(acts[i], out=acts[i + 1], code=c["pool_code"][i],
+                                          same=nd["hout"] * 2 != nd["hin"])
             lvl = fm_level.get(i)
             if side is not None and lvl in self.SIDE_HEADS:
                 ev = torch.cuda.Event()
@@ -307,7 +308,7 @@ class SSDEngine:
             g_out = gacts[i + 1]
             assert written[i + 1]
             if nd["kind"] == "pool":
-                ops.maxpool2x2_bwd(acts[i], acts[i + 1], g_out, out=gacts[i])
+                ops.maxpool2x2_bwd_argmax(c["pool_code"][i], g_out, acts[i].shape, out=gacts[i])
                 written[i] = True
                 continue
             wt, bt = self.conv_params[i]

@@ -329,6 +329,31 @@ def maxpool2x2_fwd(x, same=False):
     return y
 
 
+def maxpool2x2_fwd_argmax(x, same=False, out=None, code=None):
+    """Pooling that also records the winner of every window (4-bit codes, u32 per 8 channels) for maxpool2x2_bwd_argmax."""
+    L = _lib.lib()
+    _bf(x)
+    B, H, W, C = x.shape
+    Ho, Wo = ((H + 1) // 2, (W + 1) // 2) if same else (H // 2, W // 2)
+    if out is None:
+        out = torch.empty((B, Ho, Wo, C), dtype=torch.bfloat16, device=x.device)
+    if code is None:
+        code = torch.empty((B, Ho, Wo, C // 8), dtype=torch.int32, device=x.device)
+    _lib.check(L.ssd_maxpool2x2_fwd_argmax(_ptr(x), _ptr(out), _ptr(code), B, H, W, C, Ho, Wo, _stream()))
+    return out, code
+
+
+def maxpool2x2_bwd_argmax(code, dy, x_shape, out=None):
+    L = _lib.lib()
+    _bf(dy)
+    B, H, W, C = x_shape
+    _, Ho, Wo, _ = dy.shape
+    if out is None:
+        out = torch.empty(tuple(x_shape), dtype=torch.bfloat16, device=dy.device)
+    _lib.check(L.ssd_maxpool2x2_bwd_argmax(_ptr(code), _ptr(dy), _ptr(out), B, H, W, C, Ho, Wo, _stream()))
+    return out
+
+
 def maxpool2x2_bwd(x, y, dy, out=None):
     L = _lib.lib()
     _bf(x); _bf(y); _bf(dy)

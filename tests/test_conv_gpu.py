@@ -249,6 +249,11 @@ def test_maxpool(ops, H, same):
     want = xr.grad * (x.float() > 0)
     assert torch.equal(dx * (x.float() > 0), dx)
     assert (dx - want).abs().max().item() == 0
+    # the recorded-winner form used in training gives the same bits
+    y2, code = ops.maxpool2x2_fwd_argmax(x.cuda(), same=same)
+    assert torch.equal(y2, y)
+    dx2 = ops.maxpool2x2_bwd_argmax(code, dy.cuda(), x.shape).float().cpu()
+    assert torch.equal(dx2, dx)
 
 
 def test_image_prep(ops):

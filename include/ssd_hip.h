@@ -186,6 +186,9 @@ int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias
                           size_t ws_bytes, void* stream);
 /* w bf16 [Cout][k][k][Cin] -> w_t bf16 [Cin][k][k][Cout_pad], spatially flipped (data-gradient operand) */
 int ssd_weight_transpose(const void* w, void* w_t, int Cout, int ksize, int Cin, int Cout_pad, void* stream);
+/* the same for `ntensors` weight tensors in one launch: desc = device array of int64 rows {w, w_t, Cout, ksize, Cin,
+ * Cout_pad} (device addresses and sizes), max_tiles = max over tensors of ceil(Cout_pad/32)*ceil(Cin/32)*ksize^2 */
+int ssd_weight_transpose_batched(const long long* desc, int ntensors, int max_tiles, void* stream);
 int ssd_cast_bf16(const float* src, void* dst, long long n, void* stream);
 /* image f32 [B,H,W,3] -> bf16 [B,H,W,8]; normalize != 0 applies (x-0.5)*2 (models/ssd_model.py:214) */
 int ssd_image_prep(const float* img, void* out, int B, int H, int W, int normalize, void* stream);

@@ -45,6 +45,7 @@ _SIGNATURES = {
     "ssd_image_prep": (ctypes.c_int, [VP, VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, VP]),
     "ssd_maxpool2x2_fwd": (ctypes.c_int, [VP, VP] + [ctypes.c_int] * 6 + [VP]),
     "ssd_maxpool2x2_bwd": (ctypes.c_int, [VP, VP, VP, VP] + [ctypes.c_int] * 6 + [VP]),
+    "ssd_weight_transpose_batched": (ctypes.c_int, [VP, ctypes.c_int, ctypes.c_int, VP]),
     "ssd_maxpool2x2_fwd_argmax": (ctypes.c_int, [VP, VP, VP] + [ctypes.c_int] * 6 + [VP]),
     "ssd_maxpool2x2_bwd_argmax": (ctypes.c_int, [VP, VP, VP] + [ctypes.c_int] * 6 + [VP]),
     "ssd_head_grad_pack": (ctypes.c_int, [VP, VP, VP] + [ctypes.c_int] * 7 + [VP]),

@@ -2325,6 +2325,37 @@ __global__ void k_weight_transpose(const bf16_raw* __restrict__ w, bf16_raw* __r
     wt[i] = v;
 }
 
+// All transposed copies of a network in ONE launch: blockIdx.y = tensor, descriptor rows {src, dst, Cout, K, Cin, Cout_pad}
+// (device array of int64), blockIdx.x = 32x32 (co, ci) tile x tap; the tile goes through LDS so that both the read (ci
+// contiguous) and the write (co contiguous) are 64-byte runs.  33 launches of the per-tensor kernel cost 0.26 ms per step.
+__global__ __launch_bounds__(256) void k_weight_transpose_batched(const long long* __restrict__ desc) {
+    __shared__ bf16_raw tile[32][33];
+    const long long* d = desc + (long long)blockIdx.y * 6;
+    const bf16_raw* w = reinterpret_cast<const bf16_raw*>(d[0]);
+    bf16_raw* wt = reinterpret_cast<bf16_raw*>(d[1]);
+    const int Cout = (int)d[2], K = (int)d[3], Cin = (int)d[4], Cout_pad = (int)d[5];
+    const int tco = (Cout_pad + 31) >> 5, tci = (Cin + 31) >> 5;
+    int t = blockIdx.x;
+    if (t >= tco * tci * K * K) return;
+    const int tap = t % (K * K); t /= K * K;
+    const int ci0 = (t % tci) * 32, co0 = (t / tci) * 32;
+    const int kh = tap / K, kw = tap - kh * K;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;                 // 32 x 8
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int co = co0 + ty + 8 * j, ci = ci0 + tx;
+        bf16_raw v = 0;
+        if (co < Cout && ci < Cin) v = w[(((long long)co * K + (K - 1 - kh)) * K + (K - 1 - kw)) * Cin + ci];
+        tile[ty + 8 * j][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ci = ci0 + ty + 8 * j, co = co0 + tx;
+        if (ci < Cin && co < Cout_pad) wt[(((long long)ci * K + kh) * K + kw) * Cout_pad + co] = tile[tx][ty + 8 * j];
+    }
+}
+
 // f32 -> bf16 cast (weights after an optimizer step)
 __global__ void k_cast_bf16(const float* __restrict__ src, bf16_raw* __restrict__ dst, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -3052,6 +3083,12 @@ int ssd_weight_transpose(const void* w, void* w_t, int Cout, int ksize, int Cin,
     const long long total = (long long)Cin * ksize * ksize * Cout_pad;
     hipLaunchKernelGGL(k_weight_transpose, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        static_cast<const bf16_raw*>(w), static_cast<bf16_raw*>(w_t), Cout, ksize, ksize, Cin, Cout_pad);
+    return ssd_launch_status();
+}
+
+int ssd_weight_transpose_batched(const long long* desc, int ntensors, int max_tiles, void* stream) {
+    if (!desc || ntensors <= 0 || max_tiles <= 0) return SSD_ERR_VALUE;
+    hipLaunchKernelGGL(k_weight_transpose_batched, dim3((unsigned)max_tiles, (unsigned)ntensors), dim3(256), 0, (hipStream_t)stream, desc);
     return ssd_launch_status();
 }
 

@@ -183,10 +183,19 @@ class SSDEngine:
         """bf16 copy (if not already written by the optimizer kernel) + transposed copies for the data gradient."""
         if cast:
             ops.cast_bf16(self.param, self.param_bf16)
-        for i, wt in self.w_t.items():
-            ops.weight_transpose(self.view(self.conv_params[i][0], self.param_bf16), wt.shape[-1], out=wt)
-        for lvl, wt in enumerate(self.head_w_t):
-            ops.weight_transpose(self.view(self.head_params[lvl][0], self.param_bf16), wt.shape[-1], out=wt)
+        if getattr(self, "_tr_desc", None) is None:         # {src, dst, Cout, k, Cin, Cout_pad} per transposed copy
+            rows, tiles = [], 0
+            pairs = [(self.conv_params[i][0], wt) for i, wt in self.w_t.items()]
+            pairs += [(self.head_params[lvl][0], wt) for lvl, wt in enumerate(self.head_w_t)]
+            for pt, wt in pairs:
+                cout, k, _, cin = pt.shape
+                cpad = wt.shape[-1]
+                rows.append([self.view(pt, self.param_bf16).data_ptr(), wt.data_ptr(), cout, k, cin, cpad])
+                tiles = max(tiles, ((cpad + 31) // 32) * ((cin + 31) // 32) * k * k)
+            self._tr_desc = torch.tensor(rows, dtype=torch.int64, device=self.device)
+            self._tr_tiles = tiles
+        _lib.check(self.L.ssd_weight_transpose_batched(ops._ptr(self._tr_desc), self._tr_desc.shape[0], self._tr_tiles,
+                                                       ops._stream()))
 
     # ---------------------------------------------------------------- activations
     def _acts(self, B):

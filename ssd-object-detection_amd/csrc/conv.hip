@@ -235,7 +235,7 @@ template <int EPI>
 __device__ __forceinline__ bool staged_ok(const ConvGeom& g, const Epilogue& ep) {
     if (ep.slab) return false;
     if constexpr (EPI == EPI_FWD) return (g.N & 7) == 0 && (ep.ldo & 7) == 0;
-    if constexpr (EPI == EPI_DGRAD) return (g.N & 7) == 0 && (ep.ldo & 7) == 0 && !ep.accumulate;
+    if constexpr (EPI == EPI_DGRAD) return (g.N & 7) == 0 && (ep.ldo & 7) == 0;
     return true;                                // EPI_HEAD
 }
 
@@ -294,6 +294,15 @@ __device__ __forceinline__ void staged_epilogue(f32x4_t (&acc)[CT][PT], char* sm
             uint4 v = *reinterpret_cast<const uint4*>(smem + row * (BN * 2) + (((ch ^ row) & (CPR - 1)) << 4));
             const long long o = (long long)m * ep.ldo + n;
             if constexpr (EPI == EPI_DGRAD) {
+                if (ep.accumulate) {                          // out += result (two gradients meet at a feature map)
+                    const uint4 old = *reinterpret_cast<const uint4*>(ep.out + o);
+                    auto add2 = [](unsigned a, unsigned b) {
+                        const float lo = __uint_as_float(a << 16) + __uint_as_float(b << 16);
+                        const float hi = __uint_as_float(a & 0xffff0000u) + __uint_as_float(b & 0xffff0000u);
+                        return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+                    };
+                    v.x = add2(v.x, old.x); v.y = add2(v.y, old.y); v.z = add2(v.z, old.z); v.w = add2(v.w, old.w);
+                }
                 if (ep.mask_src) {                            // ReLU backward: zero where the forward activation was <= 0
                     const uint4 mk = *reinterpret_cast<const uint4*>(ep.mask_src + o);
                     auto gate = [](unsigned val, unsigned m2) {

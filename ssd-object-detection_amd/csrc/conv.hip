@@ -1211,6 +1211,128 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 
 // ------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 with 64 input and 64 output channels (block1_conv2 forward and data gradient): 1.5-2.2 GB of
+// traffic for 425 GFLOP, i.e. close to the HBM bound, and in the general patch kernel the [64][576] weight matrix
+// (72 KB) was re-streamed for every 16x16 block: more than half of the CU's L2 ingest.  Here the weights live in
+// REGISTERS for the whole kernel (a wave owns 32 output channels: 2 tiles x 9 taps x 2 k-halves = 36 A fragments,
+// 144 VGPRs), workgroups are persistent, the only LDS traffic is the halo patch (64 channels, 160-byte rows: conflict-
+// free and immediate-addressed) which is prefetched one block ahead, and the nine taps of a block run without a
+// single barrier.  The result leaves through the shared staged epilogue.
+constexpr int C64_PITCH = 160;
+constexpr int C64_PATCH = 51 * 1024;                       // 324 px x 160 B = 51840 B -> 51 DMA instructions
+constexpr int C64_STAGE = 2 * C64_PATCH;                   // [256 px][64 ch] bf16 staging tile (32 KB)
+
+template <int EPI>
+__global__ __launch_bounds__(512) void k_conv3x3_c64(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ w, ConvGeom g,
+                                                     Epilogue ep, int tiles_x, int tiles_y) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave & 3, wave_n = wave >> 2;        // pixel rows 4 wave_m + p, channels 32 wave_n + 16 c
+    const int nblocks = g.B * tiles_x * tiles_y;
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (unsigned)g.B * g.H * g.W * 64u * 2u, 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;
+
+    // patch DMA: instruction i = wave + 8j (j < 7, i < 51) fills 16-byte slots 64i..64i+63; slot q -> pixel q / 10, piece q % 10
+    // (pieces 8, 9 are the row padding).  The block origin enters through the pixel coordinates only: per-lane (py, px, piece)
+    int pcode[7];                                           // py << 16 | px << 8 | byte offset of the piece, -1 = padding
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int q = (wave + 8 * j) * 64 + lane;
+        const int pp = q / 10, sl = q - pp * 10;
+        const int py = pp / PATCH_W, px = pp - py * PATCH_W;
+        pcode[j] = (sl < 8 && pp < PATCH_PIX && wave + 8 * j < 51) ? ((py << 16) | (px << 8) | (sl * 16)) : -1;
+    }
+    auto issue_patch = [&](int t, int buf) {
+        int r = t;
+        const int tx = r % tiles_x; r /= tiles_x;
+        const int ty = r % tiles_y;
+        const int b = r / tiles_y;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            if (wave + 8 * j < 51) {
+                const int iy = ty * 16 - 1 + (pcode[j] >> 16), ix = tx * 16 - 1 + ((pcode[j] >> 8) & 255);
+                const bool ok = pcode[j] >= 0 && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+                const unsigned off = (unsigned)((b * g.H + iy) * g.W + ix) * 128u + (unsigned)(pcode[j] & 255);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)(smem + buf * C64_PATCH + (wave + 8 * j) * 1024), 16,
+                                                         ok ? off : OOB, 0, 0, 0);
+            }
+        }
+    };
+    if ((int)blockIdx.x < nblocks) issue_patch(blockIdx.x, 0);
+
+    // weights -> registers: A fragment (tile c, tap, k-half ks): lane (row = lane & 15, fk = lane >> 4) holds
+    // w[32 wave_n + 16 c + row][tap][32 ks + 8 fk .. +7]   (w is [N][9][64]; rows >= N are zero)
+    const int frow = lane & 15, fk = lane >> 4;
+    bf16x8_t fw[2][9][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int n = wave_n * 32 + c * 16 + frow;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (n < g.N) v = *reinterpret_cast<const uint4*>(w + (unsigned)n * 576u + (unsigned)(tap * 64 + ks * 32 + fk * 8));
+                fw[c][tap][ks] = *reinterpret_cast<const bf16x8_t*>(&v);
+            }
+    }
+    const int xbase = (4 * wave_m * PATCH_W + frow) * C64_PITCH + fk * 16;
+
+    int it = 0, prev_st = 0;
+    for (int t = blockIdx.x; t < nblocks; t += gridDim.x, ++it) {
+        const int cur = it & 1;
+        // this block's patch (issued one block ago) is older than the epilogue stores issued since: wait for all but
+        // those (prev_st = wave-uniform lower bound of the store instructions of the previous epilogue)
+        if (prev_st >= 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else if (prev_st == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        else if (prev_st == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        else if (prev_st == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + (int)gridDim.x < nblocks) issue_patch(t + gridDim.x, cur ^ 1);
+        int r = t;
+        const int tx = r % tiles_x; r /= tiles_x;
+        const int ty = r % tiles_y;
+        const int b = r / tiles_y;
+        const int y0 = ty * 16, x0 = tx * 16;
+        const int pb = cur * C64_PATCH + xbase;
+        f32x4_t acc[2][4];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[c][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8_t fx[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    fx[p] = *reinterpret_cast<const bf16x8_t*>(smem + pb + ((p + tap / 3) * PATCH_W + tap % 3) * C64_PITCH + ks * 64);
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[c][tap][ks], fx[p], acc[c][p], 0, 0, 0);
+                // 144 VGPRs hold the weights: keep the compiler from hoisting several steps of patch fragments on top of
+                // them (it spills otherwise); the partner wave on the SIMD covers the read latency
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        auto row_to_m = [&](int row) {
+            const int y = y0 + (row >> 4), xx = x0 + (row & 15);
+            return (y < g.Ho && xx < g.Wo) ? (b * g.Ho + y) * g.Wo + xx : -1;
+        };
+        staged_epilogue<EPI, 256, 64, 2, 4, 512>(acc, smem + C64_STAGE, g, ep, 0, wave_m * 64, wave_n * 32, tid, row_to_m);
+        // store instructions of that epilogue with at least one active lane (its loop: iteration i, wave w covers the
+        // 8 pixels x = 8 (w & 1) .. +7 of block row 4 i + (w >> 1))
+        prev_st = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) prev_st += (y0 + 4 * i + (wave >> 1) < g.Ho && x0 + 8 * (wave & 1) < g.Wo) ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // First layer, forward: 3x3 / stride 1 / pad 1, 8 input channels (3 image channels + padding), 64 output channels,
 // bias + ReLU.  33 us of MFMA work against 830 MB of traffic: the kernel is organised around the stores.  A workgroup
 // owns a 16x16 block: the 18x18 halo patch is 5 KB (one 16-byte pixel per DMA lane), the whole [64][72] weight matrix
@@ -2563,7 +2685,7 @@ __global__ void k_head_grad_pack(const bf16_raw* __restrict__ dloc, const bf16_r
 struct Knob { const char* name; int value; bool init; };
 Knob g_knobs[] = {{"SSD_ABLATE", 0, false}, {"SSD_DGRAD_S2", 0, false}, {"SSD_CONV_VARIANT", 0, false}, {"SSD_CONV_PATCH", 0, false},
                   {"SSD_CONV_TILE", 0, false}, {"SSD_SPLITK", 0, false}, {"SSD_WGRAD_DMA", 0, false}, {"SSD_WGRAD_PATCH", 0, false},
-                  {"SSD_WGRAD_PATCH_SINGLE", 0, false}, {"SSD_WGRAD_PATCH_SHAPE", 0, false}, {"SSD_WGRAD_TILE", 0, false}, {"SSD_CONV_PATCH_FORM", 0, false}, {"SSD_CONV_PATCH_FLAT", 0, false}, {"SSD_WGRAD_FIRST", 0, false}, {"SSD_CONV_FIRST", 0, false}, {"SSD_WGRAD_PATCH_XCD", 0, false}};
+                  {"SSD_WGRAD_PATCH_SINGLE", 0, false}, {"SSD_WGRAD_PATCH_SHAPE", 0, false}, {"SSD_WGRAD_TILE", 0, false}, {"SSD_CONV_PATCH_FORM", 0, false}, {"SSD_CONV_PATCH_FLAT", 0, false}, {"SSD_WGRAD_FIRST", 0, false}, {"SSD_CONV_FIRST", 0, false}, {"SSD_WGRAD_PATCH_XCD", 0, false}, {"SSD_CONV_C64", 0, false}};
 Knob* find_knob(const char* name) {
     for (Knob& k : g_knobs) if (!strcmp(k.name, name)) return &k;
     return nullptr;
@@ -2610,6 +2732,20 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
     ep.slab = nullptr;
     ep.ksplit = 1;
     const unsigned gm = (unsigned)((g.M + 127) / 128);
+    if constexpr (EPI != EPI_HEAD) {
+        if (knob("SSD_CONV_C64", 1) && igemm_variant() >= 1 && g.KH == 3 && g.KW == 3 && g.mul == 1 && g.div == 1 && g.pad_t == 1 &&
+            g.pad_l == 1 && g.C == 64 && g.N == 64 && g.ldw == 576 && g.H == g.Ho && g.W == g.Wo && g.H >= 16 && g.W >= 16 &&
+            !ep.accumulate && (ep.ldo & 7) == 0 && (long long)g.B * g.H * g.W * 64 < (1ll << 31) - 16) {
+            const int tiles_x = (g.Wo + 15) / 16, tiles_y = (g.Ho + 15) / 16;
+            const int nblocks = g.B * tiles_x * tiles_y;
+            constexpr int lds = 2 * C64_PATCH + 32768;
+            auto kern = k_conv3x3_c64<EPI>;
+            static bool set = false;
+            if (!set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return SSD_ERR_LAUNCH; set = true; }
+            hipLaunchKernelGGL(kern, dim3((unsigned)(nblocks < 256 ? nblocks : 256)), dim3(512), lds, s, xp, wp, g, ep, tiles_x, tiles_y);
+            return ssd_launch_status();
+        }
+    }
     // LDS-patch kernel: 3x3 / stride 1 / pad 1 with N <= SSD_CONV_PATCH (default 256); beyond 128 channels only when
     // the 16x16 blocks waste little of the map (75x75 and larger: <= 14 %; 38x38 would waste 37 %)
     const int use_patch = knob("SSD_CONV_PATCH", 256);

@@ -52,6 +52,7 @@ CASES = [
     (5, 3, 3, 128, 256, 3, 1, "valid"),      # 256x256 GEMM weight gradient, VALID, tiny M
     (2, 38, 38, 64, 192, 3, 1, "same"),      # LDS-patch kernel on strip blocks (narrow map, N > 128)
     (3, 19, 19, 128, 320, 3, 1, "same"),     # strip blocks spanning images, two channel chunks x three channel tiles
+    (5, 70, 45, 64, 64, 3, 1, "same"),       # 64 -> 64 kernel (weights in registers, persistent), ragged blocks
 ]
 
 

@@ -167,6 +167,12 @@ int ssd_nms(const float* score, const int32_t* cls, const float* box, const uint
 int ssd_conv2d_fwd(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin,
                    int Cout, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int relu, void* ws,
                    size_t ws_bytes, void* stream);
+/* Conv2D + bias + ReLU followed by MaxPool2D 2x2 / stride 2 (models/ssd_model.py:77-84: block1_conv2 -> block1_pool etc.):
+ * y as ssd_conv2d_fwd, y_pool [B,Hp,Wp,Cout] and pool_code as ssd_maxpool2x2_fwd_argmax of y.  Layers served by a
+ * 16x16-block kernel pool the tile they already hold on chip; otherwise two launches.  Cout % 8 == 0. */
+int ssd_conv2d_fwd_pool(const void* x, const void* w, const float* bias, void* y, void* y_pool, void* pool_code, int B, int H,
+                        int W, int Cin, int Cout, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int relu, int Hp,
+                        int Wp, void* ws, size_t ws_bytes, void* stream);
 /* One pyramid level's loc+conf heads as ONE 3x3 SAME GEMM (N = per_cell*(4+classes); weight rows: loc filters
  * then conf filters), written straight into the concatenated outputs loc[B,A,4] / conf[B,A,classes]
  * (:155-167: the Reshape + Concatenate are the store addressing). */

@@ -36,6 +36,7 @@ _SIGNATURES = {
     "ssd_nms_max_candidates": (ctypes.c_int, []),
     "ssd_nms": (ctypes.c_int, [VP, VP, VP, VP, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, VP, VP, VP]),
     "ssd_conv2d_fwd": (ctypes.c_int, [VP, VP, VP, VP] + [ctypes.c_int] * 12 + [VP, ctypes.c_size_t, VP]),
+    "ssd_conv2d_fwd_pool": (ctypes.c_int, [VP, VP, VP, VP, VP, VP] + [ctypes.c_int] * 14 + [VP, ctypes.c_size_t, VP]),
     "ssd_conv2d_head_fwd": (ctypes.c_int, [VP, VP, VP, VP, VP] + [ctypes.c_int] * 8 + [VP, ctypes.c_size_t, VP]),
     "ssd_conv2d_bwd_data": (ctypes.c_int, [VP, VP, VP, VP] + [ctypes.c_int] * 12 + [VP, ctypes.c_size_t, VP]),
     "ssd_conv2d_bwd_weight_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 7),

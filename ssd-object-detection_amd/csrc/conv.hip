@@ -105,6 +105,11 @@ struct Epilogue {
     // applies the epilogue to their fixed-order sum
     float* slab;
     int ksplit;
+    // FWD, 16x16-block kernels only: also write the 2x2 / stride-2 max pooling of this layer's output (and the winner
+    // codes of k_maxpool_fwd_argmax), computed from the staged tile: saves the pooling kernel's re-read of the output
+    bf16_raw* pool_out;                      // [B][pool_h][pool_w][N] or null
+    unsigned* pool_code;                     // [B][pool_h][pool_w][N/8]
+    int pool_h, pool_w;
 };
 
 __device__ __forceinline__ float bf2f(bf16_raw v) { return __uint_as_float((unsigned)v << 16); }
@@ -239,9 +244,9 @@ __device__ __forceinline__ bool staged_ok(const ConvGeom& g, const Epilogue& ep)
     return true;                                // EPI_HEAD
 }
 
-template <int EPI, int BM, int BN, int CT, int PT, int NT, typename RowMap>
+template <int EPI, int BM, int BN, int CT, int PT, int NT, typename RowMap, typename PoolMap>
 __device__ __forceinline__ void staged_epilogue(f32x4_t (&acc)[CT][PT], char* smem, const ConvGeom& g, const Epilogue& ep,
-                                                int n0, int wrow0, int wcol0, int tid, RowMap row_to_m) {
+                                                int n0, int wrow0, int wcol0, int tid, RowMap row_to_m, PoolMap pool_index) {
     constexpr int CPR = BN / 8;                 // 16-byte chunks per tile row
     const int lane = tid & 63;
     __syncthreads();
@@ -315,7 +320,51 @@ __device__ __forceinline__ void staged_epilogue(f32x4_t (&acc)[CT][PT], char* sm
             }
             *reinterpret_cast<uint4*>(ep.out + o) = v;
         }
+        if constexpr (EPI == EPI_FWD && BM == 256) {
+            // fused 2x2 pooling of a 16x16 block tile (rows = 16 y + x): pooled pixel (py, px) <- tile rows of (2py+dy, 2px+dx)
+            if (ep.pool_out) {
+                for (int idx = tid; idx < 64 * CPR; idx += NT) {
+                    const int pp = idx / CPR, ch = idx - pp * CPR;
+                    const int py = pp >> 3, px = pp & 7;
+                    const int n = n0 + ch * 8;
+                    const long long po = pool_index(py, px);
+                    if (po < 0 || n >= g.N) continue;
+                    float best[8];
+                    unsigned pos[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { best[k] = -INFINITY; pos[k] = 4u; }
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx) {
+                            const int row = (2 * py + dy) * 16 + 2 * px + dx;
+                            if (row_to_m(row) < 0) continue;
+                            const uint4 v = *reinterpret_cast<const uint4*>(smem + row * (BN * 2) + (((ch ^ row) & (CPR - 1)) << 4));
+                            const unsigned wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                const float f = (k & 1) ? __uint_as_float(wds[k >> 1] & 0xffff0000u) : __uint_as_float(wds[k >> 1] << 16);
+                                if (f > best[k]) { best[k] = f; pos[k] = (unsigned)(2 * dy + dx); }
+                            }
+                        }
+                    unsigned o4[4], cw = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o4[k] = (__float_as_uint(best[2 * k]) >> 16) | (__float_as_uint(best[2 * k + 1]) & 0xffff0000u);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) cw |= (best[k] > 0.f ? pos[k] : 4u) << (4 * k);
+                    *reinterpret_cast<uint4*>(ep.pool_out + po * g.N + n) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+                    ep.pool_code[po * (g.N >> 3) + (n >> 3)] = cw;
+                }
+            }
+        }
     }
+}
+
+// callers without a pooling stage
+template <int EPI, int BM, int BN, int CT, int PT, int NT, typename RowMap>
+__device__ __forceinline__ void staged_epilogue(f32x4_t (&acc)[CT][PT], char* smem, const ConvGeom& g, const Epilogue& ep,
+                                                int n0, int wrow0, int wcol0, int tid, RowMap row_to_m) {
+    staged_epilogue<EPI, BM, BN, CT, PT, NT>(acc, smem, g, ep, n0, wrow0, wcol0, tid, row_to_m, [](int, int) { return -1ll; });
 }
 
 // split-K finalize: out = epilogue(sum over splits of slab[split][m][n..n+3] + bias)
@@ -1194,7 +1243,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const int y = y0 + (row >> 4), xx = x0 + (row & 15);
             return (y < g.Ho && xx < g.Wo) ? (b * g.Ho + y) * g.Wo + xx : -1;
         };
-        staged_epilogue<EPI, 256, BN, CT, PT, 512>(acc, smem, g, ep, n0, wave_m * 64, wave_n * (16 * CT), tid, row_to_m);
+        auto pool_index = [&](int py, int px) -> long long {
+            if (flat) return -1;
+            const int gy = (y0 >> 1) + py, gx = (x0 >> 1) + px;
+            return (gy < ep.pool_h && gx < ep.pool_w) ? ((long long)b * ep.pool_h + gy) * ep.pool_w + gx : -1;
+        };
+        staged_epilogue<EPI, 256, BN, CT, PT, 512>(acc, smem, g, ep, n0, wave_m * 64, wave_n * (16 * CT), tid, row_to_m, pool_index);
         return;
     }
     int mrow[PT];
@@ -1323,7 +1377,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_c64(const bf16_raw* __restrict_
             const int y = y0 + (row >> 4), xx = x0 + (row & 15);
             return (y < g.Ho && xx < g.Wo) ? (b * g.Ho + y) * g.Wo + xx : -1;
         };
-        staged_epilogue<EPI, 256, 64, 2, 4, 512>(acc, smem + C64_STAGE, g, ep, 0, wave_m * 64, wave_n * 32, tid, row_to_m);
+        auto pool_index = [&](int py, int px) -> long long {
+            const int gy = (y0 >> 1) + py, gx = (x0 >> 1) + px;
+            return (gy < ep.pool_h && gx < ep.pool_w) ? ((long long)b * ep.pool_h + gy) * ep.pool_w + gx : -1;
+        };
+        staged_epilogue<EPI, 256, 64, 2, 4, 512>(acc, smem + C64_STAGE, g, ep, 0, wave_m * 64, wave_n * 32, tid, row_to_m, pool_index);
         // store instructions of that epilogue with at least one active lane (its loop: iteration i, wave w covers the
         // 8 pixels x = 8 (w & 1) .. +7 of block row 4 i + (w >> 1))
         prev_st = 0;
@@ -2685,7 +2743,7 @@ __global__ void k_head_grad_pack(const bf16_raw* __restrict__ dloc, const bf16_r
 struct Knob { const char* name; int value; bool init; };
 Knob g_knobs[] = {{"SSD_ABLATE", 0, false}, {"SSD_DGRAD_S2", 0, false}, {"SSD_CONV_VARIANT", 0, false}, {"SSD_CONV_PATCH", 0, false},
                   {"SSD_CONV_TILE", 0, false}, {"SSD_SPLITK", 0, false}, {"SSD_WGRAD_DMA", 0, false}, {"SSD_WGRAD_PATCH", 0, false},
-                  {"SSD_WGRAD_PATCH_SINGLE", 0, false}, {"SSD_WGRAD_PATCH_SHAPE", 0, false}, {"SSD_WGRAD_TILE", 0, false}, {"SSD_CONV_PATCH_FORM", 0, false}, {"SSD_CONV_PATCH_FLAT", 0, false}, {"SSD_WGRAD_FIRST", 0, false}, {"SSD_CONV_FIRST", 0, false}, {"SSD_WGRAD_PATCH_XCD", 0, false}, {"SSD_CONV_C64", 0, false}};
+                  {"SSD_WGRAD_PATCH_SINGLE", 0, false}, {"SSD_WGRAD_PATCH_SHAPE", 0, false}, {"SSD_WGRAD_TILE", 0, false}, {"SSD_CONV_PATCH_FORM", 0, false}, {"SSD_CONV_PATCH_FLAT", 0, false}, {"SSD_WGRAD_FIRST", 0, false}, {"SSD_CONV_FIRST", 0, false}, {"SSD_WGRAD_PATCH_XCD", 0, false}, {"SSD_CONV_C64", 0, false}, {"SSD_CONV_POOL_FUSE", 0, false}};
 Knob* find_knob(const char* name) {
     for (Knob& k : g_knobs) if (!strcmp(k.name, name)) return &k;
     return nullptr;
@@ -2725,7 +2783,7 @@ int igemm_variant() {                       // SSD_CONV_VARIANT=0: register-stag
 
 template <int EPI>
 int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue& ep_in, hipStream_t s, void* ws = nullptr,
-                 size_t ws_bytes = 0) {
+                 size_t ws_bytes = 0, bool* pooled = nullptr) {
     const bf16_raw* xp = static_cast<const bf16_raw*>(x);
     const bf16_raw* wp = static_cast<const bf16_raw*>(w);
     Epilogue ep = ep_in;
@@ -2743,6 +2801,7 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
             static bool set = false;
             if (!set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return SSD_ERR_LAUNCH; set = true; }
             hipLaunchKernelGGL(kern, dim3((unsigned)(nblocks < 256 ? nblocks : 256)), dim3(512), lds, s, xp, wp, g, ep, tiles_x, tiles_y);
+            if (pooled && ep.pool_out) *pooled = true;
             return ssd_launch_status();
         }
     }
@@ -2777,6 +2836,7 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
             if (g.N <= 64) { if (flat) SSD_LAUNCH_P32(64, true); else SSD_LAUNCH_P32(64, false); }
             else { if (flat) SSD_LAUNCH_P32(128, true); else SSD_LAUNCH_P32(128, false); }
 #undef SSD_LAUNCH_P32
+            if (pooled && ep.pool_out && !flat && (g.N & 7) == 0 && (ep.ldo & 7) == 0 && !(g.ablate & 8)) *pooled = true;
             return ssd_launch_status();
         }
         if (g.N <= 64) {
@@ -2931,6 +2991,25 @@ int ssd_conv2d_fwd(const void* x, const void* w, const float* bias, void* y, int
     Epilogue ep = {};
     ep.bias = bias; ep.relu = relu; ep.out = static_cast<bf16_raw*>(y); ep.ldo = Cout;
     return launch_igemm<EPI_FWD>(x, w, g, ep, (hipStream_t)stream, ws, ws_bytes);
+}
+
+int ssd_conv2d_fwd_pool(const void* x, const void* w, const float* bias, void* y, void* y_pool, void* pool_code, int B, int H,
+                        int W, int Cin, int Cout, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int relu, int Hp,
+                        int Wp, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !w || !y || !y_pool || !pool_code || !geom_ok(B, H, W, Cin, Ho, Wo, Cout, ksize) || stride <= 0 || Cout % 8)
+        return SSD_ERR_VALUE;
+    if ((Hp != Ho / 2 && Hp != (Ho + 1) / 2) || (Wp != Wo / 2 && Wp != (Wo + 1) / 2) || Hp <= 0 || Wp <= 0) return SSD_ERR_VALUE;
+    const ConvGeom g = make_geom(B, H, W, Cin, Ho, Wo, Cout, ksize, ksize, stride, 1, pad_t, pad_l);
+    Epilogue ep = {};
+    ep.bias = bias; ep.relu = relu; ep.out = static_cast<bf16_raw*>(y); ep.ldo = Cout;
+    if (knob("SSD_CONV_POOL_FUSE", 1)) {
+        ep.pool_out = static_cast<bf16_raw*>(y_pool); ep.pool_code = static_cast<unsigned*>(pool_code); ep.pool_h = Hp; ep.pool_w = Wp;
+    }
+    bool pooled = false;
+    const int rc = launch_igemm<EPI_FWD>(x, w, g, ep, (hipStream_t)stream, ws, ws_bytes, &pooled);
+    if (rc != SSD_OK || pooled) return rc;
+    // this layer is not served by a 16x16-block kernel: pool in a second launch
+    return ssd_maxpool2x2_fwd_argmax(y, y_pool, pool_code, B, Ho, Wo, Cout, Hp, Wp, stream);
 }
 
 int ssd_conv2d_head_fwd(const void* x, const void* w, const float* bias, void* loc, void* conf, int B, int H, int W,

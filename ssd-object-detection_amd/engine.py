@@ -250,9 +250,15 @@ class SSDEngine:
         for i, nd in enumerate(self.nodes):
             if nd["kind"] == "conv":
                 wt, bt = self.conv_params[i]
-                ops.conv2d_fwd(acts[i], self.view(wt, self.param_bf16), self.view(bt, self.param), nd["stride"],
-                               nd["pt"], nd["pl"], nd["hout"], nd["hout"], True, out=acts[i + 1], ws=self._ws)
-            else:
+                nxt = self.nodes[i + 1] if i + 1 < len(self.nodes) else None
+                if nxt is not None and nxt["kind"] == "pool":      # conv + the pooling behind it in one call
+                    ops.conv2d_fwd_pool(acts[i], self.view(wt, self.param_bf16), self.view(bt, self.param), nd["stride"],
+                                        nd["pt"], nd["pl"], nd["hout"], nd["hout"], True, nxt["hout"] * 2 != nxt["hin"],
+                                        out=acts[i + 1], pool_out=acts[i + 2], code=c["pool_code"][i + 1], ws=self._ws)
+                else:
+                    ops.conv2d_fwd(acts[i], self.view(wt, self.param_bf16), self.view(bt, self.param), nd["stride"],
+                                   nd["pt"], nd["pl"], nd["hout"], nd["hout"], True, out=acts[i + 1], ws=self._ws)
+            elif i == 0 or self.nodes[i - 1]["kind"] != "conv":
                 ops.maxpool2x2_fwd_argmax(acts[i], out=acts[i + 1], code=c["pool_code"][i],
                                           same=nd["hout"] * 2 != nd["hin"])
             lvl = fm_level.get(i)

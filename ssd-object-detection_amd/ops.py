@@ -265,6 +265,25 @@ def conv2d_fwd(x, w, bias, stride, pad_t, pad_l, Ho, Wo, relu, out=None, ws=None
     return out
 
 
+def conv2d_fwd_pool(x, w, bias, stride, pad_t, pad_l, Ho, Wo, relu, same, out=None, pool_out=None, code=None, ws=None):
+    """conv2d_fwd followed by maxpool2x2_fwd_argmax of its output, fused on chip where the kernel allows."""
+    L = _lib.lib()
+    _bf(x); _bf(w)
+    B, H, W, Cin = x.shape
+    Cout, k = w.shape[0], w.shape[1]
+    Hp, Wp = ((Ho + 1) // 2, (Wo + 1) // 2) if same else (Ho // 2, Wo // 2)
+    if out is None:
+        out = torch.empty((B, Ho, Wo, Cout), dtype=torch.bfloat16, device=x.device)
+    if pool_out is None:
+        pool_out = torch.empty((B, Hp, Wp, Cout), dtype=torch.bfloat16, device=x.device)
+    if code is None:
+        code = torch.empty((B, Hp, Wp, Cout // 8), dtype=torch.int32, device=x.device)
+    wbuf = _splitk_ws(ws)
+    _lib.check(L.ssd_conv2d_fwd_pool(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), _ptr(pool_out), _ptr(code), B, H, W, Cin, Cout, k,
+                                     stride, pad_t, pad_l, Ho, Wo, 1 if relu else 0, Hp, Wp, _ptr(wbuf), wbuf.numel(), _stream()))
+    return out, pool_out, code
+
+
 def conv2d_head_fwd(x, w, bias, loc, conf, per_cell, classes, level_off, ws=None):
     L = _lib.lib()
     _bf(x); _bf(w); _bf(loc); _bf(conf)

@@ -257,6 +257,21 @@ def test_maxpool(ops, H, same):
     assert torch.equal(dx2, dx)
 
 
+@pytest.mark.parametrize("case", [(2, 46, 64, 64, False), (2, 75, 128, 256, True), (1, 33, 64, 96, True), (2, 19, 128, 128, False)])
+def test_conv_fwd_pool_fused(ops, case):
+    """conv + ReLU + 2x2 pooling in one call == the separate calls, bit for bit (the fused form pools the tile the
+    convolution kernel holds on chip; layers without a 16x16-block kernel fall back to two launches)."""
+    B, H, Cin, Cout, same = case
+    g = torch.Generator().manual_seed(H)
+    x = torch.randn((B, H, H, Cin), generator=g).bfloat16().cuda()
+    w = (torch.randn((Cout, 3, 3, Cin), generator=g) / np.sqrt(9 * Cin)).bfloat16().cuda()
+    bias = (torch.randn((Cout,), generator=g) * 0.1).cuda()
+    y, yp, code = ops.conv2d_fwd_pool(x, w, bias, 1, 1, 1, H, H, True, same)
+    y_ref = ops.conv2d_fwd(x, w, bias, 1, 1, 1, H, H, True)
+    yp_ref, code_ref = ops.maxpool2x2_fwd_argmax(y_ref, same=same)
+    assert torch.equal(y, y_ref) and torch.equal(yp, yp_ref) and torch.equal(code, code_ref)
+
+
 def test_image_prep(ops):
     img = torch.rand((2, 30, 30, 3))
     out = ops.image_prep(img.cuda()).float().cpu()

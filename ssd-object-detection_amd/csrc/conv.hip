@@ -2088,10 +2088,14 @@ __global__ __launch_bounds__(512) void k_conv3x3_wgrad_patch(const bf16_raw* __r
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
-    // eight waves (two per SIMD, equal work): wave w owns output-channel tiles {2(w&1), 2(w&1)+1} x input-channel
-    // tile (w>>1) x all nine taps = 18 accumulator tiles
+    // eight waves, two per SIMD (waves w and w + 4 share one), with UNEQUAL roles: the "loader" waves 0-3 issue all of
+    // the next block's LDS-DMA (an LDS-DMA instruction holds its wave for 100-200 cycles, ~2700 cycles per block) and own
+    // LTAPS = 4 taps x four co-tiles = 16 accumulator tiles of input-channel tile ct = w; their partners 4-7 issue no
+    // DMA and own the other five taps = 20 tiles.  While a loader is stuck in its DMA issue the partner keeps the SIMD's MFMA
+    // pipe busy; with equal shares and everybody issuing DMA both waves of a SIMD stalled together (measured: 459 us
+    // with, 340 us without the DMA, same clock, the difference all in barrier waits).
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ap = wave & 1, ct = wave >> 1;
+    const int ct = wave & 3, role = wave >> 2;              // role 0: loader, first taps; role 1: the rest
     // work units (split, co tile, ci chunk), chunk fastest.  XCD-aware order (workgroup L runs on XCD L % 8): `xg`
     // consecutive units -- the channel groups that walk the SAME pixel blocks -- sit on one XCD, so that a dY tile /
     // X patch is fetched into that L2 once instead of once per group (xg from the host: a divisor of the unit count
@@ -2108,7 +2112,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wgrad_patch(const bf16_raw* __r
     const int ntiles = g.B * tiles_x * tiles_y;
     const int t_begin = split * tiles_per_split, t_end = min(ntiles, t_begin + tiles_per_split);
 
-    // DMA ownership: instruction i of the dY tile / of the patch goes to wave i % 8
+    // DMA ownership: instruction i of the dY tile / of the patch goes to loader wave i % 4
     auto issue_dma = [&](int t, int buf) {
         int r = t;
         const int tx = r % tiles_x; r /= tiles_x;
@@ -2117,8 +2121,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_wgrad_patch(const bf16_raw* __r
         const int y0 = ty * BH, x0 = tx * G::BW;
         char* base = smem + buf * G::BUF;
 #pragma unroll
-        for (int j = 0; j < G::DY_INSTR / 8; ++j) {
-            const int i = wave + 8 * j;                     // 8 pixel slots x 128 B per instruction
+        for (int j = 0; j < G::DY_INSTR / 4; ++j) {
+            const int i = ct + 4 * j;                       // 8 pixel slots x 128 B per instruction
             const int kk = 8 * i + (lane >> 3), sl = lane & 7;
             const int c16 = (((sl >> 1) ^ wp_key(kk)) << 1) | (sl & 1);
             const int pg = kk >> 4;                         // pair group -> (row pair, column group)
@@ -2131,8 +2135,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_wgrad_patch(const bf16_raw* __r
             __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(base + i * 1024), 16, 0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < (G::P_INSTR + 7) / 8; ++j) {
-            const int i = wave + 8 * j;
+        for (int j = 0; j < (G::P_INSTR + 3) / 4; ++j) {
+            const int i = ct + 4 * j;
             if (i < G::P_INSTR) {
                 const int pp = 8 * i + (lane >> 3), sl = lane & 7;
                 const int c16 = (((sl >> 1) ^ wp_key(pp)) << 1) | (sl & 1);
@@ -2146,32 +2150,32 @@ __global__ __launch_bounds__(512) void k_conv3x3_wgrad_patch(const bf16_raw* __r
         }
     };
 
-    f32x4_t acc[2][9];
-    f32x4_t accb[2];
+    constexpr int LTAPS = 4;                                // taps of a loader wave; its partner takes the other 9 - LTAPS (3 | 6 measured the same)
+    f32x4_t acc[4][9 - LTAPS];                              // [co tile][tap of this role]
+    f32x4_t accb[4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
+    for (int a = 0; a < 4; ++a) {
         accb[a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t9 = 0; t9 < 9; ++t9) acc[a][t9] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int t5 = 0; t5 < 9 - LTAPS; ++t5) acc[a][t5] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
-    const bool do_bias = slab_b != nullptr && chunk == 0 && ct == 0;
+    const bool do_bias = slab_b != nullptr && chunk == 0 && ct == 0 && role == 1;
     bf16x8_t ones;
 #pragma unroll
     for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
 
-    // single_buf: one LDS buffer so that TWO workgroups share a CU and hide each other's DMA latency;
-    // otherwise two buffers in one workgroup, next block's DMA in flight during this block's MFMAs
-    if (t_begin < t_end) issue_dma(t_begin, 0);
+    // two LDS buffers: the next block's DMA is in flight during this block's MFMAs
+    if (t_begin < t_end && role == 0) issue_dma(t_begin, 0);
     // MFMA k index <-> block pixel: k-step ks, `half` select pair group pg = 2ks + half = (row pair rp, column group xg);
     // within it lane group gq and the lane select row 2rp + (gq>>1), column 8xg + 4*(gq&1) + (li>>2), so that the 8 rows
     // of a half-wave instruction are consecutive pixels.  All address arithmetic is hoisted: the dY row of a lane is
     // base + immediate, and a patch row is one of eight per-lane bases (pixel offset mod 8) + immediate.
     const int gq = lane >> 4, li = lane & 15;
-    int abase[2];
+    int abase[4];
     {
         const int kk0 = (gq >> 1) * 8 + (gq & 1) * 4 + (li >> 2);
 #pragma unroll
-        for (int a = 0; a < 2; ++a) abase[a] = kk0 * 128 + (((2 * ap + a) ^ wp_key(kk0)) << 5) + (li & 3) * 8;
+        for (int a = 0; a < 4; ++a) abase[a] = kk0 * 128 + ((a ^ wp_key(kk0)) << 5) + (li & 3) * 8;
     }
     int gbase[8];
     {
@@ -2180,67 +2184,71 @@ __global__ __launch_bounds__(512) void k_conv3x3_wgrad_patch(const bf16_raw* __r
         for (int r = 0; r < 8; ++r) gbase[r] = G::DY_BYTES + (p0 + r) * 128 + ((ct ^ wp_key(p0 + r)) << 5) + (li & 3) * 8;
     }
     typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
-    // fragments of one k-step: 4 dY reads + 18 patch reads (all with immediate offsets)
-    struct Frag { bf16x8_t fa[2]; bf16x8_t fb[9]; };
-    auto load_frag = [&](Frag& f, const int (&ab)[2], const int (&gb)[8], auto ks_tag) {
-        constexpr int ks = decltype(ks_tag)::value;
-#pragma unroll
-        for (int half = 0; half < 2; ++half)
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-                reinterpret_cast<s16x4_t*>(&f.fa[a])[half] =
-                    __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + ab[a] + (ks * 2 + half) * 2048));
-#pragma unroll
-        for (int t9 = 0; t9 < 9; ++t9)
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int pg = (ks * 2 + half) < G::NPG ? (ks * 2 + half) : 0;   // padding group: any finite data (dY is zero there)
-                const int rp = pg / BW8, xg = pg - rp * BW8;
-                const int ctap = (2 * rp + t9 / 3) * G::PW + xg * 8 + (t9 % 3);   // compile-time pixel offset
-                reinterpret_cast<s16x4_t*>(&f.fb[t9])[half] =
-                    __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + gb[ctap & 7] + (ctap >> 3) * 1024));
-            }
-    };
-    // the block loop exists twice (with / without the bias MFMAs) so that its body has no branch: the k-steps of
+    // fragments of one k-step: 8 dY reads + 2 patch reads per tap (all with immediate offsets)
+    struct Frag { bf16x8_t fa[4]; bf16x8_t fb[9 - LTAPS]; };
+    // the block loop exists per role (and with / without the bias MFMAs) so that its body has no branch: the k-steps of
     // a block are one basic block, software-pipelined by hand (fragments of k-step ks+1 are read during the MFMAs of ks)
-    auto run = [&](auto bias_tag) {
+    auto run = [&](auto role_tag, auto bias_tag) {
+        constexpr int ROLE = decltype(role_tag)::value;
         constexpr bool BIAS = decltype(bias_tag)::value;
+        constexpr int TAP0 = ROLE == 0 ? 0 : LTAPS, NTAP = ROLE == 0 ? LTAPS : 9 - LTAPS;
+        auto load_frag = [&](Frag& f, const int (&ab)[4], const int (&gb)[8], auto ks_tag) {
+            constexpr int ks = decltype(ks_tag)::value;
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    reinterpret_cast<s16x4_t*>(&f.fa[a])[half] =
+                        __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + ab[a] + (ks * 2 + half) * 2048));
+#pragma unroll
+            for (int t5 = 0; t5 < NTAP; ++t5)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int tap = TAP0 + t5;
+                    const int pg = (ks * 2 + half) < G::NPG ? (ks * 2 + half) : 0;   // padding group: any finite data (dY is zero there)
+                    const int rp = pg / BW8, xg = pg - rp * BW8;
+                    const int ctap = (2 * rp + tap / 3) * G::PW + xg * 8 + (tap % 3);   // compile-time pixel offset
+                    reinterpret_cast<s16x4_t*>(&f.fb[t5])[half] =
+                        __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + gb[ctap & 7] + (ctap >> 3) * 1024));
+                }
+        };
         for (int t = t_begin; t < t_end; ++t) {
-            const int cur = single_buf ? 0 : (t - t_begin) & 1;
+            const int cur = (t - t_begin) & 1;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (!single_buf && t + 1 < t_end) issue_dma(t + 1, cur ^ 1);
+            if constexpr (ROLE == 0) { if (t + 1 < t_end) issue_dma(t + 1, cur ^ 1); }
             const int boff = cur * G::BUF;
-            int ab[2], gb[8];
+            int ab[4], gb[8];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) ab[a] = abase[a] + boff;
+            for (int a = 0; a < 4; ++a) ab[a] = abase[a] + boff;
 #pragma unroll
             for (int r = 0; r < 8; ++r) gb[r] = gbase[r] + boff;
             Frag f0, f1;
             auto mma = [&](const Frag& f) {
 #pragma unroll
-                for (int t9 = 0; t9 < 9; ++t9)
+                for (int t5 = 0; t5 < NTAP; ++t5)
 #pragma unroll
-                    for (int a = 0; a < 2; ++a)
-                        acc[a][t9] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.fa[a], f.fb[t9], acc[a][t9], 0, 0, 0);
+                    for (int a = 0; a < 4; ++a)
+                        acc[a][t5] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.fa[a], f.fb[t5], acc[a][t5], 0, 0, 0);
                 if constexpr (BIAS) {
 #pragma unroll
-                    for (int a = 0; a < 2; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.fa[a], ones, accb[a], 0, 0, 0);
+                    for (int a = 0; a < 4; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.fa[a], ones, accb[a], 0, 0, 0);
                 }
             };
-            // interleave: one MFMA, then one LDS read of the next k-step (22 reads over 18-20 MFMAs)
+            // interleave: one MFMA, then one LDS read of the next k-step
             auto weave = [&]() {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                constexpr int NR = 8 + 2 * NTAP, NM = 4 * NTAP;          // reads of the next k-step, MFMAs of this one
+                constexpr int PAIRS = NR < NM ? NR : NM;
+                if constexpr (NR > PAIRS) {                             // more reads than MFMAs: the surplus goes first
+                    __builtin_amdgcn_sched_group_barrier(0x100, NR - PAIRS, 0);
                 }
 #pragma unroll
-                for (int i = 0; i < 14; ++i) {
+                for (int i = 0; i < PAIRS; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
-                if constexpr (BIAS) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                constexpr int REST = NM - PAIRS + (BIAS ? 4 : 0);
+                if constexpr (REST > 0) __builtin_amdgcn_sched_group_barrier(0x008, REST, 0);
             };
             static_assert(G::KS == 8, "the hand-unrolled pipeline below assumes eight k-steps per block");
             load_frag(f0, ab, gb, std::integral_constant<int, 0>{});
@@ -2252,34 +2260,34 @@ __global__ __launch_bounds__(512) void k_conv3x3_wgrad_patch(const bf16_raw* __r
             load_frag(f0, ab, gb, std::integral_constant<int, 6>{}); mma(f1); weave();
             load_frag(f1, ab, gb, std::integral_constant<int, 7>{}); mma(f0); weave();
             mma(f1);
-            if (single_buf && t + 1 < t_end) {
-                __syncthreads();                                 // everybody is done reading the buffer
-                issue_dma(t + 1, 0);
-            }
         }
     };
-    if (do_bias) run(std::true_type{}); else run(std::false_type{});
+    if (role == 0) run(std::integral_constant<int, 0>{}, std::false_type{});
+    else if (do_bias) run(std::integral_constant<int, 1>{}, std::true_type{});
+    else run(std::integral_constant<int, 1>{}, std::false_type{});
     // slab[split][co][tap][ci]  (dW layout [Cout][kh][kw][Cin], rows = ldy channels)
     const int ktot = g.ldw;
     float* out = slab_w + (long long)split * g.N * ktot;
+    const int tap0 = role == 0 ? 0 : LTAPS, ntap = role == 0 ? LTAPS : 9 - LTAPS;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int t9 = 0; t9 < 9; ++t9) {
-            const int col = t9 * g.C + ci0 + ct * 16 + (lane & 15);
+        for (int t5 = 0; t5 < 9 - LTAPS; ++t5) {
+            if (t5 >= ntap) continue;
+            const int col = (tap0 + t5) * g.C + ci0 + ct * 16 + (lane & 15);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int co = co0 + (2 * ap + a) * 16 + (lane >> 4) * 4 + j;
-                if (co < g.N) out[(long long)co * ktot + col] = acc[a][t9][j];
+                const int co = co0 + a * 16 + (lane >> 4) * 4 + j;
+                if (co < g.N) out[(long long)co * ktot + col] = acc[a][t5][j];
             }
         }
     if (do_bias && (lane & 15) == 0) {
         float* ob = slab_b + (long long)split * g.N;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int co = co0 + (2 * ap + a) * 16 + (lane >> 4) * 4 + j;
+                const int co = co0 + a * 16 + (lane >> 4) * 4 + j;
                 if (co < g.N) ob[co] = accb[a][j];
             }
     }
@@ -3197,7 +3205,7 @@ int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias
         float* slab_w = static_cast<float*>(ws);
         float* slab_b = slab_w + (size_t)ns * ldy * ktot;
         hipStream_t s = (hipStream_t)stream;
-        const int single = knob("SSD_WGRAD_PATCH_SINGLE", 0);
+        const int single = 0;                                   // (single-buffer mode was dropped with the loader-wave kernel)
         const int groups = (Cin / 64) * ((Cout + 63) / 64), nunits = groups * ns;
         // units per XCD group: all channel groups of a split when that leaves >= 16 groups of units, else halve
         int xg = groups;

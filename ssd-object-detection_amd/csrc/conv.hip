@@ -3207,9 +3207,15 @@ int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias
         hipStream_t s = (hipStream_t)stream;
         const int single = 0;                                   // (single-buffer mode was dropped with the loader-wave kernel)
         const int groups = (Cin / 64) * ((Cout + 63) / 64), nunits = groups * ns;
-        // units per XCD group: all channel groups of a split when that leaves >= 16 groups of units, else halve
-        int xg = groups;
-        while (xg > 1 && nunits / xg < 16 && xg % 2 == 0) xg /= 2;
+        // units per XCD group: the largest divisor of the channel-group count whose round-robin placement (group i on
+        // XCD i % 8) keeps every XCD within ~7 % of its fair share of workgroups
+        int xg = 1;
+        for (int d = groups; d >= 1; --d) {
+            if (groups % d) continue;
+            const int ngr = (nunits + d - 1) / d;
+            const int load = ((ngr + 7) / 8) * d, fair = (nunits + 7) / 8;
+            if (load * 100 <= fair * 107) { xg = d; break; }
+        }
         if (!knob("SSD_WGRAD_PATCH_XCD", 1)) xg = 1;
         const unsigned grid = (unsigned)(8 * xg * ((nunits + 8 * xg - 1) / (8 * xg)));
         int bh, bw;

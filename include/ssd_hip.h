@@ -198,6 +198,16 @@ int ssd_weight_transpose_batched(const long long* desc, int ntensors, int max_ti
 int ssd_cast_bf16(const float* src, void* dst, long long n, void* stream);
 /* image f32 [B,H,W,3] -> bf16 [B,H,W,8]; normalize != 0 applies (x-0.5)*2 (models/ssd_model.py:214) */
 int ssd_image_prep(const float* img, void* out, int B, int H, int W, int normalize, void* stream);
+/* Input pipeline on the device for a ragged batch of decoded uint8 RGB images: '/255'
+ * (data_loaders/coco/make_dataset.py:117), cv2.resize(image, (S, S)) with its default INTER_LINEAR
+ * (data_loaders/ssd/make_dataset.py:40) and, if normalize != 0, (x-0.5)*2 (models/ssd_model.py:214) -> bf16 [B,S,S,8].
+ * src: the images back to back (H x W x 3 bytes each), src_off int64 [B] byte offset of each image, src_hw int32 [B][2]. */
+int ssd_image_resize_prep(const void* src, const int64_t* src_off, const int32_t* src_hw, void* out, int B, int S,
+                          int normalize, void* stream);
+/* Ground-truth boxes of the same batch: COCO [x, y, w, h] in pixels (top-left) -> centre form (coco/make_dataset.py:132)
+ * divided by the image size (ssd/make_dataset.py:43-44).  gt_off int32 [B+1] as in ssd_match_encode. */
+int ssd_box_prep(const float* box_tlwh, const int32_t* gt_off, const int32_t* src_hw, float* box_out, int B, int total_gt,
+                 void* stream);
 /* MaxPool2D 2x2 stride 2 (VGG block pools: VALID; models/ssd_model.py:84: SAME -> Ho = ceil(H/2)) */
 int ssd_maxpool2x2_fwd(const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, void* stream);
 /* pooling backward fused with the ReLU backward of the layer that produced x */

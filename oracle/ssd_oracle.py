@@ -340,3 +340,60 @@ def adam_step(p, g, m, v, t, lr, beta1=0.9, beta2=0.999, eps=1e-7):
     lr_t = lr * math.sqrt(1 - beta2 ** t) / (1 - beta1 ** t)
     p = p - lr_t * m / (np.sqrt(v) + eps)
     return p, m, v
+
+
+# --------------------------------------------------------------------------------------
+# N1: input-side preprocessing.  PARITY UNPINNED for the resize: cv2 is not installable in the build
+# image, so `resize_bilinear` restates OpenCV's published INTER_LINEAR rule for float images (what
+# data_loaders/ssd/make_dataset.py:40 calls with the default interpolation) instead of being checked against it.
+# --------------------------------------------------------------------------------------
+def _linear_coords(n_dst, n_src):
+    """cv2.resize INTER_LINEAR source taps of every destination index: fx = (float)((d + 0.5) * scale - 0.5),
+    s = floor(fx), f = fx - s, with s < 0 -> (0, f = 0) and s >= n-1 -> (n-1, f = 0); second tap clamped to n-1."""
+    scale = float(n_src) / float(n_dst)
+    d = np.arange(n_dst, dtype=np.float64)
+    fx = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(fx).astype(np.int64)
+    f = (fx - s.astype(np.float32)).astype(np.float32)
+    lo = s < 0
+    s[lo] = 0
+    f[lo] = 0.0
+    hi = s >= n_src - 1
+    s[hi] = n_src - 1
+    f[hi] = 0.0
+    s1 = np.minimum(s + 1, n_src - 1)
+    return s, s1, f
+
+
+def resize_bilinear(img_f32, size):
+    """img_f32 [H,W,C] float32 -> [size,size,C] float32; horizontal pass then vertical pass, float32 products and sums
+    (no fused multiply-add), as OpenCV's generic float path does."""
+    H, W, _ = img_f32.shape
+    x0, x1, fx = _linear_coords(size, W)
+    y0, y1, fy = _linear_coords(size, H)
+    a0 = (np.float32(1.0) - fx)[None, :, None]
+    a1 = fx[None, :, None]
+    rows = (img_f32[:, x0, :] * a0).astype(np.float32) + (img_f32[:, x1, :] * a1).astype(np.float32)   # [H, size, C]
+    rows = rows.astype(np.float32)
+    b0 = (np.float32(1.0) - fy)[:, None, None]
+    b1 = fy[:, None, None]
+    out = (rows[y0] * b0).astype(np.float32) + (rows[y1] * b1).astype(np.float32)
+    return out.astype(np.float32)
+
+
+def image_resize_prep(img_u8, size=300, normalize=True):
+    """uint8 [H,W,3] -> float32 [size,size,3]: /255 in float64 then float32 (data_loaders/coco/make_dataset.py:117 +
+    the float32 TensorSpec :140), cv2.resize (ssd/make_dataset.py:40), (x - 0.5) * 2 (models/ssd_model.py:214)."""
+    x = (img_u8.astype(np.float64) / 255.0).astype(np.float32)
+    x = resize_bilinear(x, size)
+    if normalize:
+        x = ((x - np.float32(0.5)) * np.float32(2.0)).astype(np.float32)
+    return x
+
+
+def box_prep(box_tlwh, h, w):
+    """COCO [x, y, w, h] pixels -> centre form (coco/make_dataset.py:132) divided by [w, h, w, h] (ssd/make_dataset.py:43-44),
+    float32 as the TensorSpecs make it."""
+    b = np.asarray(box_tlwh, np.float32).copy()
+    b[:, :2] = b[:, :2] + b[:, 2:] / np.float32(2.0)
+    return (b / np.array([w, h, w, h], np.float32)).astype(np.float32)

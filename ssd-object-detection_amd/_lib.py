@@ -44,6 +44,8 @@ _SIGNATURES = {
     "ssd_weight_transpose": (ctypes.c_int, [VP, VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, VP]),
     "ssd_cast_bf16": (ctypes.c_int, [VP, VP, ctypes.c_longlong, VP]),
     "ssd_image_prep": (ctypes.c_int, [VP, VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, VP]),
+    "ssd_image_resize_prep": (ctypes.c_int, [VP, VP, VP, VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, VP]),
+    "ssd_box_prep": (ctypes.c_int, [VP, VP, VP, VP, ctypes.c_int, ctypes.c_int, VP]),
     "ssd_maxpool2x2_fwd": (ctypes.c_int, [VP, VP] + [ctypes.c_int] * 6 + [VP]),
     "ssd_maxpool2x2_bwd": (ctypes.c_int, [VP, VP, VP, VP] + [ctypes.c_int] * 6 + [VP]),
     "ssd_weight_transpose_batched": (ctypes.c_int, [VP, ctypes.c_int, ctypes.c_int, VP]),

@@ -22,6 +22,8 @@ PER_FILE = {
     # sNaN-quieting v_max(x,x) in front of every fmax/fmin (inputs are finite by contract).
     "match.hip": ["-ffp-contract=off", "-fno-honor-nans"],
     "detect.hip": ["-ffp-contract=off"],
+    # the resize restates cv2's float arithmetic product by product (HIP's __fmul_rn / __fadd_rn are plain * and +)
+    "prep.hip": ["-ffp-contract=off"],
 }
 
 

@@ -39,3 +39,20 @@ def synth_batch_gt(first_index, batch, n_t=None):
         cls_list.append(c)
         box_list.append(b)
     return cls_list, box_list
+
+
+def synth_raw_sample(image_index, n_t=None):
+    """A sample as the COCO reader hands it over BEFORE the SSD loader's preprocessing (reference
+    data_loaders/coco/make_dataset.py:108-134 without the /255): decoded uint8 RGB image of a COCO-like size
+    (short side 240..480, long side <= 640), cls f32[n], box f32[n,4] = [x, y, w, h] top-left in pixels.
+    Same ground truth as synth_gt(image_index) once preprocessed."""
+    rng = np.random.default_rng(9876 + image_index)
+    h = int(rng.integers(240, 481))
+    w = int(rng.integers(240, 641))
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    cls, box = synth_gt(image_index, n_t)
+    scale = np.array([w, h, w, h], np.float32)
+    px = box * scale                                        # centre form in pixels
+    tlwh = px.copy()
+    tlwh[:, :2] = px[:, :2] - px[:, 2:] / np.float32(2.0)
+    return img, cls, tlwh.astype(np.float32)

@@ -103,6 +103,25 @@ class SSDObjectDetectionModel:
         cls, loc, mask = ops.match_encode(*gt, self._pset, self.cfg.thresh)
         return img, (cls, loc, mask)
 
+    def make_batch_raw(self, images_u8, cls_list, box_tlwh_list):
+        """The same from what the COCO reader yields before any preprocessing: decoded uint8 RGB images
+        of arbitrary sizes and COCO [x, y, w, h] pixel boxes.  '/255', cv2.resize to the network size, '(x-0.5)*2'
+        (reference data_loaders/coco/make_dataset.py:117, data_loaders/ssd/make_dataset.py:40-44, models/ssd_model.py:214)
+        and the box conversion run on the device; returns the prepared bf16 network input instead of the f32 image."""
+        hw = np.array([im.shape[:2] for im in images_u8], np.int32)
+        sizes = [int(im.size) for im in images_u8]
+        off = np.zeros(len(sizes), np.int64)
+        off[1:] = np.cumsum(sizes[:-1])
+        flat = np.concatenate([np.ascontiguousarray(im, np.uint8).reshape(-1) for im in images_u8])
+        dev = self.device
+        hw_d = torch.from_numpy(hw).to(dev)
+        x = ops.image_resize_prep(torch.from_numpy(flat).to(dev), torch.from_numpy(off).to(dev), hw_d,
+                                  int(self.cfg.input_shape[0]), True)
+        gt_box, gt_cls, gt_off, total, max_nt = ops.pack_gt(box_tlwh_list, cls_list, device=dev)
+        gt_box = ops.box_prep(gt_box, gt_off, hw_d) if total else gt_box
+        cls, loc, mask = ops.match_encode(gt_box, gt_cls, gt_off, total, max_nt, self._pset, self.cfg.thresh)
+        return x, (cls, loc, mask)
+
     # ------------------------------------------------------------------ loss (A6)
     @staticmethod
     def _ssd_loss(y_true, y_pred):
@@ -132,7 +151,10 @@ class SSDObjectDetectionModel:
             self._reducer = GradReducer(eng.grad, [t.offset for t in eng.tensors], blocks, eng.block,
                                         eng.clip_range_in_place)
         for i in range(0, batch_size, batch_step):
-            x = ops.image_prep(image[i:i + batch_step].contiguous(), normalize=False)
+            if image.dtype == torch.bfloat16:          # already prepared on the device (make_batch_raw)
+                x = image[i:i + batch_step]
+            else:
+                x = ops.image_prep(image[i:i + batch_step].contiguous(), normalize=False)
             pred_loc, pred_conf = eng.forward(x)
             _, info = self._ssd_loss((gt_cls[i:i + batch_step], gt_bbox[i:i + batch_step], gt_mask[i:i + batch_step]),
                                      (pred_loc, pred_conf))

@@ -338,6 +338,28 @@ def conv2d_bwd_weight(x, dy, Cout, k, stride, pad_t, pad_l, dw=None, dbias=None,
     return dw, dbias
 
 
+def image_resize_prep(src, src_off, src_hw, S=300, normalize=True, out=None):
+    """Ragged batch of uint8 RGB images (src: flat u8 buffer, src_off i64 [B] byte offsets, src_hw i32 [B,2]) ->
+    network input bf16 [B,S,S,8]: /255, cv2.resize INTER_LINEAR, (x-0.5)*2  (reference lines in include/ssd_hip.h)."""
+    L = _lib.lib()
+    _dev(src, torch.uint8); _dev(src_off, torch.int64); _dev(src_hw, torch.int32)
+    B = src_hw.shape[0]
+    if out is None:
+        out = torch.empty((B, S, S, 8), dtype=torch.bfloat16, device=src.device)
+    _lib.check(L.ssd_image_resize_prep(_ptr(src), _ptr(src_off), _ptr(src_hw), _ptr(out), B, S, 1 if normalize else 0, _stream()))
+    return out
+
+
+def box_prep(box_tlwh, gt_off, src_hw):
+    """COCO [x,y,w,h] pixel boxes of a batch (concatenated) -> relative centre form, per image size."""
+    L = _lib.lib()
+    _dev(box_tlwh, torch.float32); _dev(gt_off, torch.int32); _dev(src_hw, torch.int32)
+    total = box_tlwh.shape[0]
+    out = torch.empty_like(box_tlwh)
+    _lib.check(L.ssd_box_prep(_ptr(box_tlwh), _ptr(gt_off), _ptr(src_hw), _ptr(out), src_hw.shape[0], total, _stream()))
+    return out
+
+
 def maxpool2x2_fwd(x, same=False):
     L = _lib.lib()
     _bf(x)

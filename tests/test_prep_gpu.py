@@ -1,0 +1,72 @@
+"""N1: device-side input preprocessing vs the oracle restatement."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import ssd_oracle as O                                   # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16(a):
+    return torch.from_numpy(a).bfloat16().float().numpy()
+
+
+def test_image_resize_prep_ragged_batch():
+    import ssd_object_detection_amd.ops as ops
+    rng = np.random.default_rng(7)
+    shapes = [(480, 640), (300, 300), (37, 53), (600, 123), (1, 1), (299, 301)]
+    imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in shapes]
+    flat = np.concatenate([i.reshape(-1) for i in imgs])
+    off = np.cumsum([0] + [i.size for i in imgs[:-1]]).astype(np.int64)
+    hw = np.array(shapes, np.int32)
+    for normalize in (True, False):
+        out = ops.image_resize_prep(torch.from_numpy(flat).cuda(), torch.from_numpy(off).cuda(), torch.from_numpy(hw).cuda(),
+                                    300, normalize).float().cpu().numpy()
+        assert out.shape == (len(imgs), 300, 300, 8)
+        assert np.all(out[..., 3:] == 0)
+        for b, img in enumerate(imgs):
+            want = O.image_resize_prep(img, 300, normalize)
+            # same float32 arithmetic on both sides: identical after the bf16 rounding of the network input
+            assert np.array_equal(out[b, ..., :3], _bf16(want)), (b, shapes[b], np.abs(out[b, ..., :3] - _bf16(want)).max())
+
+
+def test_box_prep():
+    import ssd_object_detection_amd.ops as ops
+    rng = np.random.default_rng(8)
+    hw = np.array([(480, 640), (300, 300), (37, 53)], np.int32)
+    counts = [5, 0, 3]
+    boxes = (rng.random((sum(counts), 4)) * 100).astype(np.float32)
+    off = np.cumsum([0] + counts).astype(np.int32)
+    got = ops.box_prep(torch.from_numpy(boxes).cuda(), torch.from_numpy(off).cuda(), torch.from_numpy(hw).cuda()).cpu().numpy()
+    for b in range(3):
+        sl = slice(off[b], off[b + 1])
+        if counts[b]:
+            assert np.array_equal(got[sl], O.box_prep(boxes[sl], h=hw[b, 0], w=hw[b, 1]))
+
+
+def test_train_step_from_raw_inputs():
+    """End to end from decoded images: make_batch_raw == the host pipeline (oracle resize + make_batch) bit for bit,
+    and a train step runs on its output."""
+    from ssd_object_detection_amd import optimizers
+    from ssd_object_detection_amd.models import SSDObjectDetectionModel
+    from ssd_object_detection_amd.data_loaders.synthetic import synth_raw_sample
+    model = SSDObjectDetectionModel(classes=80, log_dir="gpurun_out/prep_test", seed=2, timestamp_dir=False)
+    samples = [synth_raw_sample(i) for i in range(4)]
+    imgs, cls_l, box_l = zip(*samples)
+    x, (cls, loc, mask) = model.make_batch_raw(list(imgs), list(cls_l), list(box_l))
+    # host pipeline of the reference, restated: /255, resize, boxes, then the f32 make_batch
+    host_imgs = [O.image_resize_prep(im, 300, normalize=False) for im in imgs]
+    host_boxes = [O.box_prep(b, h=im.shape[0], w=im.shape[1]) for im, b in zip(imgs, box_l)]
+    img_f32, (cls2, loc2, mask2) = model.make_batch(host_imgs, list(cls_l), host_boxes)
+    import ssd_object_detection_amd.ops as ops
+    x2 = ops.image_prep(img_f32.contiguous(), normalize=False)
+    assert torch.equal(x, x2)
+    assert torch.equal(cls, cls2) and torch.equal(mask, mask2) and torch.equal(loc, loc2)
+    _, _, info = model._train_step(x, cls, loc, mask, optimizers.Adam(1e-3))
+    vals = [float(info[k]) for k in ("loc loss", "cls loss pos", "cls loss neg")]
+    assert all(np.isfinite(v) and v > 0 for v in vals)

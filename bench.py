@@ -176,6 +176,24 @@ def main():
             "frac": round(mbytes / t_match / 1e9 / PEAK_HBM_GBS, 4), "traffic": traffic,
             "algorithmic_bytes": mbytes, "us_per_image": round(t_match / B * 1e6, 4), "total_gt": total_gt}
 
+        # N1: device-side input preprocessing of a batch of COCO-sized uint8 images, HBM-bound:
+        # algorithmic bytes = the source bytes read once + the bf16 [B,300,300,8] network input written once
+        from ssd_object_detection_amd.data_loaders.synthetic import synth_raw_sample
+        raw = [synth_raw_sample(i)[0] for i in range(B)]
+        hw = np.array([r.shape[:2] for r in raw], np.int32)
+        sizes = [int(r.size) for r in raw]
+        off = np.zeros(B, np.int64)
+        off[1:] = np.cumsum(sizes[:-1])
+        flat = torch.from_numpy(np.concatenate([r.reshape(-1) for r in raw])).cuda()
+        off_d, hw_d = torch.from_numpy(off).cuda(), torch.from_numpy(hw).cuda()
+        xprep = ops.image_resize_prep(flat, off_d, hw_d, 300, True)
+        t_prep = timed(lambda: ops.image_resize_prep(flat, off_d, hw_d, 300, True, out=xprep), 20)
+        pbytes = int(sum(sizes)) + B * 300 * 300 * 8 * 2
+        result["roofline_prep"] = {
+            "bound": "hbm", "kernel": "ssd_image_resize_prep (k_image_resize_prep)", "achieved": round(pbytes / t_prep / 1e9, 1),
+            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(pbytes / t_prep / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+            "algorithmic_bytes": pbytes, "us_per_image": round(t_prep / B * 1e6, 3)}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(np, torch)
 

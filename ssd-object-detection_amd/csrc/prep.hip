@@ -36,6 +36,11 @@ __device__ __forceinline__ void src_coord(int d, double scale, int n, int& s0, i
 
 __global__ void k_image_resize_prep(const unsigned char* __restrict__ src, const long long* __restrict__ src_off,
                                     const int* __restrict__ src_hw, bf16_raw* __restrict__ out, int S, int normalize) {
+    // u8 / 255 as the reference's float64 division rounded to float32 (TensorSpec float32): 256 possible values, one
+    // per thread of the block
+    __shared__ float lut[256];
+    lut[threadIdx.x] = (float)((double)threadIdx.x / 255.0);
+    __syncthreads();
     const int b = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S * S) return;
@@ -50,11 +55,10 @@ __global__ void k_image_resize_prep(const unsigned char* __restrict__ src, const
     float v[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        // u8 / 255 as the reference's float64 division rounded to float32 (TensorSpec float32)
-        const float p00 = (float)((double)img[((long long)y0 * W + x0) * 3 + c] / 255.0);
-        const float p01 = (float)((double)img[((long long)y0 * W + x1) * 3 + c] / 255.0);
-        const float p10 = (float)((double)img[((long long)y1 * W + x0) * 3 + c] / 255.0);
-        const float p11 = (float)((double)img[((long long)y1 * W + x1) * 3 + c] / 255.0);
+        const float p00 = lut[img[((long long)y0 * W + x0) * 3 + c]];
+        const float p01 = lut[img[((long long)y0 * W + x1) * 3 + c]];
+        const float p10 = lut[img[((long long)y1 * W + x0) * 3 + c]];
+        const float p11 = lut[img[((long long)y1 * W + x1) * 3 + c]];
         // separate multiplies and adds (no contraction), horizontal pass first
         const float h0 = __fadd_rn(__fmul_rn(p00, ax0), __fmul_rn(p01, fx));
         const float h1 = __fadd_rn(__fmul_rn(p10, ax0), __fmul_rn(p11, fx));

@@ -24,12 +24,13 @@ from ..parallel import GradReducer
 from .. import optimizers as _opt
 
 logger = logging.getLogger(__name__)
+_RESTORED = object()                            # _slot_owner marker: Adam moments were loaded from a checkpoint
 
 
 class SSDObjectDetectionModel:
     class TrainConfig:
         def __init__(self, epoch, batch_size, optimizer, warmup=True, warmup_optimizer=None, warmup_step=1000,
-                     visualization_log_interval=10, split_batch=False, split_batch_size=4):
+                     visualization_log_interval=10, split_batch=False, split_batch_size=4, start_epoch=0):
             if warmup_optimizer is None:
                 warmup_optimizer = _opt.Adam(_opt.PolynomialDecay(1e-6, 1000, 0.001))
             self.epoch = epoch
@@ -41,6 +42,7 @@ class SSDObjectDetectionModel:
             self.visualization_log_interval = visualization_log_interval
             self.split_batch = split_batch
             self.split_batch_size = split_batch_size
+            self.start_epoch = start_epoch                 # > 0: resumed run (no warm-up, epochs start_epoch..epoch-1)
 
     class Config:
         def __init__(self, classes, log_dir):
@@ -168,7 +170,9 @@ class SSDObjectDetectionModel:
                 if not single:
                     eng.accumulate_clipped(first=(n_micro == 0))
             n_micro += 1
-        if self._slot_owner is not ssd_optimizer:     # Keras keeps separate slots per optimizer (warm-up vs train)
+        if self._slot_owner is _RESTORED:             # moments came from a checkpoint: the first optimizer adopts them
+            self._slot_owner = ssd_optimizer
+        elif self._slot_owner is not ssd_optimizer:   # Keras keeps separate slots per optimizer (warm-up vs train)
             eng.adam_m.zero_()
             eng.adam_v.zero_()
             self._slot_owner = ssd_optimizer
@@ -198,7 +202,7 @@ class SSDObjectDetectionModel:
         train_set, _val_set = data_loader.get_dataset()
         set_names, set_colors = data_loader.get_names_and_colors()
         batches = self.get_train_set(train_set, batch_size=cfg.batch_size)
-        if cfg.warmup:
+        if cfg.warmup and getattr(cfg, "start_epoch", 0) == 0:
             logger.info("Warm up for %s steps", cfg.warmup_step)
             step = 0
             while step < cfg.warmup_step:
@@ -214,14 +218,16 @@ class SSDObjectDetectionModel:
                 if not got:
                     break
         step = 0
-        for epoch in range(cfg.epoch):
+        for epoch in range(getattr(cfg, "start_epoch", 0), cfg.epoch):
             logger.info("Epoch %s/%s", epoch + 1, cfg.epoch)
             for image, (gt_cls, gt_bbox, gt_mask) in batches:
                 step += 1
                 _, _, info = self._train_step(image, gt_cls, gt_bbox, gt_mask, cfg.optimizer, "train", set_names,
                                               set_colors, step, cfg)
                 self._log(step, info, cfg, "train")
-            self.save(os.path.join(self.cfg.log_dir, "model_weight", "model_weight_epoch_%d.pt" % epoch))
+            self.save(os.path.join(self.cfg.log_dir, "model_weight", "model_weight_epoch_%d.pt" % epoch),
+                      extra=dict(epoch=epoch + 1, iterations=cfg.optimizer.iterations,
+                                 warmup_iterations=cfg.warmup_optimizer.iterations if cfg.warmup_optimizer else 0))
 
     def _log(self, step, info, cfg, stage):
         if step % max(1, cfg.visualization_log_interval) == 0:
@@ -250,14 +256,50 @@ class SSDObjectDetectionModel:
         keep = ops.nms(score, cls, box, cand, iou_thresh, max_cand)
         return score, cls, box, keep
 
+    def evaluate(self, samples, batch_size=32, score_thresh=0.05, iou_thresh=0.45, max_dets=100):
+        """Evaluation pass (the reference fetches its val split at models/ssd_model.py:291 and drops it):
+        samples = iterable of (image f32 [S,S,3] in [0,1], cls [n], box [n,4] relative cx,cy,w,h) as the loaders yield
+        them.  Network forward, scoring/decoding and per-class NMS run on the device; the kept detections go to
+        utils.metrics.coco_map on the host.  Returns its dict (mAP = AP@[.5:.95], AP50, AP75, per_class)."""
+        from ..utils.metrics import coco_map
+        size = float(self.cfg.input_shape[0])
+        dets, gts, buf = [], [], []
+
+        def flush():
+            if not buf:
+                return
+            img = torch.from_numpy(np.stack([b[0] for b in buf], 0)).to(self.device)
+            score, cls, box, keep = self.detect((img - 0.5) * 2, score_thresh, iou_thresh)
+            score, cls, box, keep = score.cpu().numpy(), cls.cpu().numpy(), box.cpu().numpy(), keep.cpu().numpy().astype(bool)
+            for i, (_, gcls, gbox) in enumerate(buf):
+                k = keep[i]
+                dets.append((score[i][k], cls[i][k], box[i][k]))
+                gts.append((np.asarray(gcls), np.asarray(gbox, np.float64) * size))     # pixels, like the decoded boxes
+            buf.clear()
+
+        for sample in samples:
+            buf.append(sample)
+            if len(buf) == batch_size:
+                flush()
+        flush()
+        return coco_map(dets, gts, max_dets=max_dets)
+
     # ------------------------------------------------------------------ checkpoint
-    def save(self, path="model_weight.pt"):
+    def save(self, path="model_weight.pt", extra=None):
+        """Weights + Adam moments + step count (the reference's Keras .h5 has weights only, models/ssd_model.py:405-407);
+        `extra` (e.g. optimizer iteration counters, epoch) is stored alongside for resume."""
         d = os.path.dirname(path)
         if d:
             os.makedirs(d, exist_ok=True)
-        torch.save(self._engine.state_dict(), path)
+        sd = self._engine.state_dict()
+        if extra:
+            sd["extra"] = dict(extra)
+        torch.save(sd, path)
         logger.info("Model is saved to %s", path)
 
     def load(self, path="model_weight.pt"):
-        self._engine.load_state_dict(torch.load(path, map_location="cpu", weights_only=False))
+        sd = torch.load(path, map_location="cpu", weights_only=False)
+        self._engine.load_state_dict(sd)
+        self._slot_owner = _RESTORED
         logger.info("Model is loaded from %s", path)
+        return sd.get("extra", {})

@@ -53,6 +53,17 @@ def train(config):
     optimizer = _make_optimizer(config["model"]["train"]["optimizer"], lr_scheduler)
     warmup_optimizer = _make_optimizer(config["model"]["warmup"]["optimizer"], warmup_lr_scheduler)
 
+    # resume (the reference has load() but no resume path): `model.resume: <checkpoint>` in the YAML
+    # restores weights, Adam moments, step counters and continues with the epoch after the saved one
+    start_epoch = 0
+    resume = config["model"].get("resume")
+    if resume:
+        extra = model.load(resume)
+        optimizer.iterations = int(extra.get("iterations", model.get_engine().step_count))
+        warmup_optimizer.iterations = int(extra.get("warmup_iterations", 0))
+        start_epoch = int(extra.get("epoch", 0))
+        logger.info("Resuming from %s at epoch %d (optimizer step %d)", resume, start_epoch, optimizer.iterations)
+
     os.makedirs(model.get_log_dir(), exist_ok=True)
     with open(os.path.join(model.get_log_dir(), "config.json"), "w") as f:
         json.dump(config, f, sort_keys=True, indent=4, separators=(',', ':'))
@@ -66,7 +77,8 @@ def train(config):
                                                         warmup_step=config["model"]["warmup"]["step"],
                                                         visualization_log_interval=config["model"]["log_interval"],
                                                         split_batch=config["model"]["split_train"]["enable"],
-                                                        split_batch_size=config["model"]["split_train"]["batch_size"]))
+                                                        split_batch_size=config["model"]["split_train"]["batch_size"],
+                                                        start_epoch=start_epoch))
     model.save(os.path.join(model.get_log_dir(), config["model"]["save"]))
     return model
 

@@ -1,0 +1,97 @@
+"""Per-step training scalars without per-step host syncs.
+
+The reference writes five TensorBoard scalars after EVERY step (`models/ssd_model.py:281-285`:
+`<stage>/loc loss`, `<stage>/cls loss pos`, `<stage>/cls loss neg`, `<stage>/loss`, `<stage>/lr`), each one a
+device->host read.  Here a step only enqueues one 32-byte device-to-device copy of the loss kernel's result row into
+a ring in HBM; the ring is read back in ONE transfer when it fills, at the end of an epoch, or on close, and the same
+five tags are appended to `<log_dir>/scalars.jsonl` (one JSON object per scalar: tag, step, value).  TensorBoard is not
+in the image, so the event-file encoding is out of scope; tags, steps and values are the reference's.
+
+Row layout = the loss kernel's `out8`: loc, pos, neg, total, P, N, tau, status (ops.ssd_loss).
+"""
+import json
+import os
+
+import torch
+
+TAGS = ("loc loss", "cls loss pos", "cls loss neg", "loss", "lr")
+
+
+class HardNegativeThresholdError(AssertionError):
+    """status == 2 in a logged row: the hard-negative threshold reached 0 (reference assert, models/ssd_model.py:375)."""
+
+
+class ScalarLog:
+    def __init__(self, log_dir, device, capacity=512, distributed=False, console_interval=10, logger=None):
+        self.path = os.path.join(log_dir, "scalars.jsonl")
+        self.ring = torch.zeros((capacity, 8), dtype=torch.float32, device=device)
+        self.meta = []                                   # (stage, step, lr) per filled slot, host side
+        self.capacity = capacity
+        self.distributed = bool(distributed)
+        self.console_interval = max(1, int(console_interval))
+        self.logger = logger
+        self.rows_written = 0
+        self._file = None
+
+    def record(self, stage, step, raw8, lr):
+        """Enqueue one step's scalars.  `raw8` = device f32[8] from ops.ssd_loss (stream-ordered copy, no sync)."""
+        self.ring[len(self.meta)].copy_(raw8, non_blocking=True)
+        self.meta.append((stage, int(step), float(lr)))
+        if len(self.meta) == self.capacity:
+            self.flush()
+
+    def flush(self):
+        """One device->host transfer for everything recorded since the last flush; returns the rows written."""
+        n = len(self.meta)
+        if n == 0:
+            return []
+        block = self.ring[:n]
+        if self.distributed and torch.distributed.is_initialized():
+            # losses: mean over ranks (each rank logged its own image shard); status: any rank failing counts
+            block = block.clone()
+            block[:, 7] = (block[:, 7] == 2).float()
+            torch.distributed.all_reduce(block)
+            block[:, :7] /= torch.distributed.get_world_size()
+            block[:, 7] = torch.where(block[:, 7] > 0, 2.0, 0.0)
+        host = block.cpu().numpy()                       # the only host sync
+        rows = []
+        write = (not self.distributed) or (not torch.distributed.is_initialized()) or torch.distributed.get_rank() == 0
+        if write and self._file is None:
+            os.makedirs(os.path.dirname(self.path) or ".", exist_ok=True)
+            self._file = open(self.path, "a")
+        for (stage, step, lr), r in zip(self.meta, host):
+            loc, pos, neg = float(r[0]), float(r[1]), float(r[2])
+            vals = (loc, pos, neg, loc + pos + neg, lr)  # reference :284 sums the three on the host
+            rows.append((stage, step, vals))
+            if write:
+                for tag, v in zip(TAGS, vals):
+                    self._file.write(json.dumps({"tag": stage + "/" + tag, "step": step, "value": v}) + "\n")
+                if self.logger is not None and step % self.console_interval == 0:
+                    self.logger.info("%s step %d: %s", stage, step, dict(zip(TAGS, vals)))
+        if write:
+            self._file.flush()
+        self.rows_written += n
+        self.meta.clear()
+        bad = [m for m, r in zip(rows, host) if r[7] == 2]
+        if bad:
+            raise HardNegativeThresholdError("hard-negative threshold reached 0 at %s step %d "
+                                             "(reference assert, models/ssd_model.py:375)" % (bad[0][0], bad[0][1]))
+        return rows
+
+    def close(self):
+        try:
+            self.flush()
+        finally:
+            if self._file is not None:
+                self._file.close()
+                self._file = None
+
+
+def read_scalars(path):
+    """scalars.jsonl -> {tag: [(step, value), ...]} in file order."""
+    out = {}
+    with open(path) as f:
+        for line in f:
+            d = json.loads(line)
+            out.setdefault(d["tag"], []).append((d["step"], d["value"]))
+    return out

@@ -121,3 +121,47 @@ def test_evaluate_reports_map(tmp_path):
     gts = [(s[1], np.asarray(s[2], np.float64) * 300.0) for s in samples]
     dets = [(np.ones(len(g[0])), g[0], g[1]) for g in gts]
     assert coco_map(dets, gts)["mAP"] == 1.0
+
+
+def test_scalars_are_logged_without_per_step_syncs(tmp_path):
+    """N4: the reference's five scalars per step (models/ssd_model.py:281-285) land in scalars.jsonl with
+    the values a per-step host read would have seen, while the step loop itself never synchronises the host."""
+    from ssd_object_detection_amd import optimizers
+    from ssd_object_detection_amd.data_loaders import SSDDataLoader
+    from ssd_object_detection_amd.models import SSDObjectDetectionModel
+    from ssd_object_detection_amd.utils.scalar_log import ScalarLog, TAGS, read_scalars
+    loader = SSDDataLoader("unused", dataset="synthetic", shuffle=False, mini_batch=8)
+    train, _ = loader.get_dataset()
+
+    def run(sync_every_step):
+        model = SSDObjectDetectionModel(classes=80, log_dir=str(tmp_path / ("s" if sync_every_step else "a")),
+                                        timestamp_dir=False)
+        opt = optimizers.Adam(optimizers.ExponentialDecay(1e-3, 100, 0.9))
+        batches = list(model.get_train_set(train, batch_size=4))
+        model._scalars = ScalarLog(model.get_log_dir(), model.device, capacity=64)
+        seen = []
+        model._train_step(batches[0][0], *batches[0][1], opt)               # first step builds caches (allocations sync)
+        torch.cuda.synchronize()
+        if not sync_every_step:
+            torch.cuda.set_sync_debug_mode("error")                         # any torch-side host sync now raises
+        try:
+            for step in range(1, 6):
+                image, gt = batches[step % 2]
+                _, _, info = model._train_step(image, *gt, opt)
+                model._log(step, info, None, "train")
+                if sync_every_step:
+                    seen.append([float(info[k]) for k in ("loc loss", "cls loss pos", "cls loss neg")])
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        rows = model._scalars.flush()
+        model._scalars.close()
+        return model, seen, rows
+
+    m_sync, seen, _ = run(True)
+    m_async, _, rows = run(False)
+    assert [r[1] for r in rows] == [1, 2, 3, 4, 5]
+    for (stage, step, vals), want in zip(rows, seen):
+        assert stage == "train" and list(vals[:3]) == want and vals[3] == want[0] + want[1] + want[2]
+    got = read_scalars(os.path.join(m_async.get_log_dir(), "scalars.jsonl"))
+    assert set(got) == {"train/" + t for t in TAGS} and all(len(v) == 5 for v in got.values())
+    assert torch.equal(m_sync.get_engine().param, m_async.get_engine().param)

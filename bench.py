@@ -77,7 +77,7 @@ def main():
     def step(i):
         nonlocal match_out
         img, gt = batches[i % NBATCH]
-        match_out = ops.match_encode(*gt, pset, 0.5, out=match_out)          # A3-A5 on the device
+        match_out = model.match_async(gt, out=match_out)     # A3-A5 on the device, side stream, under the forward pass
         cls, loc, mask = match_out
         model._train_step(img, cls, loc, mask, opt)
 

@@ -244,6 +244,8 @@ __device__ __forceinline__ bool staged_ok(const ConvGeom& g, const Epilogue& ep)
     return true;                                // EPI_HEAD
 }
 
+struct NoPool { __device__ long long operator()(int, int) const { return -1; } };
+
 template <int EPI, int BM, int BN, int CT, int PT, int NT, typename RowMap, typename PoolMap>
 __device__ __forceinline__ void staged_epilogue(f32x4_t (&acc)[CT][PT], char* smem, const ConvGeom& g, const Epilogue& ep,
                                                 int n0, int wrow0, int wcol0, int tid, RowMap row_to_m, PoolMap pool_index) {
@@ -320,10 +322,11 @@ __device__ __forceinline__ void staged_epilogue(f32x4_t (&acc)[CT][PT], char* sm
             }
             *reinterpret_cast<uint4*>(ep.out + o) = v;
         }
-        if constexpr (EPI == EPI_FWD && BM == 256) {
-            // fused 2x2 pooling of a 16x16 block tile (rows = 16 y + x): pooled pixel (py, px) <- tile rows of (2py+dy, 2px+dx)
+        if constexpr (EPI == EPI_FWD && !std::is_same<PoolMap, NoPool>::value) {
+            // fused 2x2 pooling of a 16-wide block tile (rows = 16 y + x, BM / 16 rows): pooled pixel (py, px) <- tile rows
+            // of (2py+dy, 2px+dx)
             if (ep.pool_out) {
-                for (int idx = tid; idx < 64 * CPR; idx += NT) {
+                for (int idx = tid; idx < (BM / 4) * CPR; idx += NT) {
                     const int pp = idx / CPR, ch = idx - pp * CPR;
                     const int py = pp >> 3, px = pp & 7;
                     const int n = n0 + ch * 8;
@@ -364,7 +367,7 @@ __device__ __forceinline__ void staged_epilogue(f32x4_t (&acc)[CT][PT], char* sm
 template <int EPI, int BM, int BN, int CT, int PT, int NT, typename RowMap>
 __device__ __forceinline__ void staged_epilogue(f32x4_t (&acc)[CT][PT], char* smem, const ConvGeom& g, const Epilogue& ep,
                                                 int n0, int wrow0, int wcol0, int tid, RowMap row_to_m) {
-    staged_epilogue<EPI, BM, BN, CT, PT, NT>(acc, smem, g, ep, n0, wrow0, wcol0, tid, row_to_m, [](int, int) { return -1ll; });
+    staged_epilogue<EPI, BM, BN, CT, PT, NT>(acc, smem, g, ep, n0, wrow0, wcol0, tid, row_to_m, NoPool{});
 }
 
 // split-K finalize: out = epilogue(sum over splits of slab[split][m][n..n+3] + bias)
@@ -1344,7 +1347,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_c64(const bf16_raw* __restrict_
         else if (prev_st == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
-        if (t + (int)gridDim.x < nblocks) issue_patch(t + gridDim.x, cur ^ 1);
+        if (t + (int)gridDim.x < nblocks && !(g.ablate & 1)) issue_patch(t + gridDim.x, cur ^ 1);
         int r = t;
         const int tx = r % tiles_x; r /= tiles_x;
         const int ty = r % tiles_y;
@@ -1363,12 +1366,17 @@ __global__ __launch_bounds__(512) void k_conv3x3_c64(const bf16_raw* __restrict_
                 bf16x8_t fx[4];
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
-                    fx[p] = *reinterpret_cast<const bf16x8_t*>(smem + pb + ((p + tap / 3) * PATCH_W + tap % 3) * C64_PITCH + ks * 64);
+                    fx[p] = *reinterpret_cast<const bf16x8_t*>(smem + ((g.ablate & 4) ? xbase : pb + ((p + tap / 3) * PATCH_W + tap % 3) * C64_PITCH + ks * 64));
+                if (g.ablate & 32) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) asm volatile("" :: "v"(fx[p]));
+                } else {
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
                     for (int p = 0; p < 4; ++p)
                         acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[c][tap][ks], fx[p], acc[c][p], 0, 0, 0);
+                }
                 // 144 VGPRs hold the weights: keep the compiler from hoisting several steps of patch fragments on top of
                 // them (it spills otherwise); the partner wave on the SIMD covers the read latency
                 __builtin_amdgcn_sched_barrier(0);
@@ -1381,12 +1389,159 @@ __global__ __launch_bounds__(512) void k_conv3x3_c64(const bf16_raw* __restrict_
             const int gy = (y0 >> 1) + py, gx = (x0 >> 1) + px;
             return (gy < ep.pool_h && gx < ep.pool_w) ? ((long long)b * ep.pool_h + gy) * ep.pool_w + gx : -1;
         };
+        if (g.ablate & 8) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) asm volatile("" :: "v"(acc[c][p]));
+            prev_st = 0;
+            continue;
+        }
         staged_epilogue<EPI, 256, 64, 2, 4, 512>(acc, smem + C64_STAGE, g, ep, 0, wave_m * 64, wave_n * 32, tid, row_to_m, pool_index);
         // store instructions of that epilogue with at least one active lane (its loop: iteration i, wave w covers the
         // 8 pixels x = 8 (w & 1) .. +7 of block row 4 i + (w >> 1))
         prev_st = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) prev_st += (y0 + 4 * i + (wave >> 1) < g.Ho && x0 + 8 * (wave & 1) < g.Wo) ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same layer, second form (default).  Timing the pieces of the kernel above on MI355X showed its
+// fragment reads (72 ds_read_b128 per wave and block = 4.6k LDS cycles per block at 128 B/clk) to cost as much as its
+// MFMAs (4.6k cycles) without overlapping them, and the epilogue (another 30 % of the time) to run with the matrix cores
+// idle because the CU holds a single workgroup.  Here
+//   * a fragment is read ONCE per patch row and reused by every tap that touches it: the wave walks the 6 patch rows of
+//     its 4 output rows, and the fragment (row r, dx, k-half) feeds the MFMAs of (dy, p = r - dy) for all valid dy --
+//     36 reads per wave and block instead of 72, issued two steps ahead of their use;
+//   * workgroups are 4 waves on an 8 x 16 block and two of them share a CU (74 KB of LDS, 256 VGPRs per wave): they
+//     drift apart, so one's epilogue (LDS turn-around, coalesced stores, fused pooling) runs under the other's MFMAs.
+constexpr int C64B_ROWS = 8;                               // block = 8 rows x 16 columns
+constexpr int C64B_PATCH_PIX = (C64B_ROWS + 2) * PATCH_W;  // 180 halo pixels
+constexpr int C64B_NDMA = (C64B_PATCH_PIX * 10 + 63) / 64; // 29 wave-instructions of 64 x 16 B
+constexpr int C64B_PATCH = C64B_NDMA * 1024;               // 29696 B per buffer
+constexpr int C64B_STAGE = 2 * C64B_PATCH;                 // [128 px][64 ch] bf16 staging tile (16 KB)
+constexpr int C64B_LDS = C64B_STAGE + 128 * 128;
+
+template <int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ w, ConvGeom g, Epilogue ep, int tiles_x, int tiles_y) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave & 1, wave_n = wave >> 1;        // output rows 4 wave_m + p, channels 32 wave_n + 16 c
+    const int nblocks = g.B * tiles_x * tiles_y;
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (unsigned)g.B * g.H * g.W * 64u * 2u, 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;
+    constexpr int NJ = (C64B_NDMA + 3) / 4;                 // DMA instructions per wave: i = wave + 4 j
+
+    int pcode[NJ];                                          // py << 16 | px << 8 | byte offset of the piece, -1 = padding
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int q = (wave + 4 * j) * 64 + lane;
+        const int pp = q / 10, sl = q - pp * 10;
+        const int py = pp / PATCH_W, px = pp - py * PATCH_W;
+        pcode[j] = (sl < 8 && pp < C64B_PATCH_PIX && wave + 4 * j < C64B_NDMA) ? ((py << 16) | (px << 8) | (sl * 16)) : -1;
+    }
+    auto issue_patch = [&](int t, int buf) {
+        int r = t;
+        const int tx = r % tiles_x; r /= tiles_x;
+        const int ty = r % tiles_y;
+        const int b = r / tiles_y;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (wave + 4 * j < C64B_NDMA) {
+                const int iy = ty * C64B_ROWS - 1 + (pcode[j] >> 16), ix = tx * 16 - 1 + ((pcode[j] >> 8) & 255);
+                const bool ok = pcode[j] >= 0 && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+                const unsigned off = (unsigned)((b * g.H + iy) * g.W + ix) * 128u + (unsigned)(pcode[j] & 255);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)(smem + buf * C64B_PATCH + (wave + 4 * j) * 1024), 16,
+                                                         ok ? off : OOB, 0, 0, 0);
+            }
+        }
+    };
+    if ((int)blockIdx.x < nblocks) issue_patch(blockIdx.x, 0);
+
+    const int frow = lane & 15, fk = lane >> 4;
+    bf16x8_t fw[2][9][2];                                   // as in k_conv3x3_c64
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int n = wave_n * 32 + c * 16 + frow;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (n < g.N) v = *reinterpret_cast<const uint4*>(w + (unsigned)n * 576u + (unsigned)(tap * 64 + ks * 32 + fk * 8));
+                fw[c][tap][ks] = *reinterpret_cast<const bf16x8_t*>(&v);
+            }
+    }
+    const int xbase = (4 * wave_m * PATCH_W + frow) * C64_PITCH + fk * 16;
+
+    int it = 0, prev_st = 0;
+    for (int t = blockIdx.x; t < nblocks; t += gridDim.x, ++it) {
+        const int cur = it & 1;
+        if (prev_st >= 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else if (prev_st == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        else if (prev_st == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        else if (prev_st == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + (int)gridDim.x < nblocks && !(g.ablate & 1)) issue_patch(t + gridDim.x, cur ^ 1);
+        int r = t;
+        const int tx = r % tiles_x; r /= tiles_x;
+        const int ty = r % tiles_y;
+        const int b = r / tiles_y;
+        const int y0 = ty * C64B_ROWS, x0 = tx * 16;
+        const int pb = cur * C64B_PATCH + xbase;
+        f32x4_t acc[2][4];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[c][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        // step s = (patch row rr = s / 6, dx = (s / 2) % 3, k-half = s & 1)
+        auto frag = [&](int s2) {
+            return *reinterpret_cast<const bf16x8_t*>(smem + pb + ((s2 / 6) * PATCH_W + (s2 / 2) % 3) * C64_PITCH + (s2 & 1) * 64);
+        };
+        bf16x8_t f0 = frag(0), f1 = frag(1);
+#pragma unroll
+        for (int s2 = 0; s2 < 36; ++s2) {
+            bf16x8_t f2 = f1;
+            if (s2 + 2 < 36) f2 = frag(s2 + 2);
+            const int rr = s2 / 6, dx = (s2 / 2) % 3, ks = s2 & 1;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int p = rr - dy;
+                if (p >= 0 && p < 4) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+                        acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[c][dy * 3 + dx][ks], f0, acc[c][p], 0, 0, 0);
+                }
+            }
+            f0 = f1; f1 = f2;
+            __builtin_amdgcn_sched_barrier(0);              // keep the reads two steps ahead, no further (144 VGPRs of weights)
+        }
+        if (g.ablate & 8) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) asm volatile("" :: "v"(acc[c][p]));
+            prev_st = 0;
+            continue;
+        }
+        auto row_to_m = [&](int row) {
+            const int y = y0 + (row >> 4), xx = x0 + (row & 15);
+            return (y < g.Ho && xx < g.Wo) ? (b * g.Ho + y) * g.Wo + xx : -1;
+        };
+        auto pool_index = [&](int py, int px) -> long long {
+            const int gy = (y0 >> 1) + py, gx = (x0 >> 1) + px;
+            return (gy < ep.pool_h && gx < ep.pool_w) ? ((long long)b * ep.pool_h + gy) * ep.pool_w + gx : -1;
+        };
+        staged_epilogue<EPI, 128, 64, 2, 4, 256>(acc, smem + C64B_STAGE, g, ep, 0, wave_m * 64, wave_n * 32, tid, row_to_m, pool_index);
+        // store instructions of that epilogue with at least one active lane (its loop: iteration i, wave w covers the
+        // 8 pixels x = 8 (w & 1) .. +7 of block row 2 i + (w >> 1)): a lower bound of what this wave issued after the DMA
+        prev_st = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) prev_st += (y0 + 2 * i + (wave >> 1) < g.Ho && x0 + 8 * (wave & 1) < g.Wo) ? 1 : 0;
     }
 }
 
@@ -2799,9 +2954,19 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
     ep.ksplit = 1;
     const unsigned gm = (unsigned)((g.M + 127) / 128);
     if constexpr (EPI != EPI_HEAD) {
-        if (knob("SSD_CONV_C64", 1) && igemm_variant() >= 1 && g.KH == 3 && g.KW == 3 && g.mul == 1 && g.div == 1 && g.pad_t == 1 &&
+        if (knob("SSD_CONV_C64", 2) && igemm_variant() >= 1 && g.KH == 3 && g.KW == 3 && g.mul == 1 && g.div == 1 && g.pad_t == 1 &&
             g.pad_l == 1 && g.C == 64 && g.N == 64 && g.ldw == 576 && g.H == g.Ho && g.W == g.Wo && g.H >= 16 && g.W >= 16 &&
             !ep.accumulate && (ep.ldo & 7) == 0 && (long long)g.B * g.H * g.W * 64 < (1ll << 31) - 16) {
+            if (knob("SSD_CONV_C64", 2) >= 2) {             // 8 x 16 blocks, two workgroups per CU
+                const int tiles_x = (g.Wo + 15) / 16, tiles_y = (g.Ho + C64B_ROWS - 1) / C64B_ROWS;
+                const int nblocks = g.B * tiles_x * tiles_y;
+                auto kern = k_conv3x3_c64b<EPI>;
+                static bool set = false;
+                if (!set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C64B_LDS) != hipSuccess) return SSD_ERR_LAUNCH; set = true; }
+                hipLaunchKernelGGL(kern, dim3((unsigned)(nblocks < 512 ? nblocks : 512)), dim3(256), C64B_LDS, s, xp, wp, g, ep, tiles_x, tiles_y);
+                if (pooled && ep.pool_out) *pooled = true;
+                return ssd_launch_status();
+            }
             const int tiles_x = (g.Wo + 15) / 16, tiles_y = (g.Ho + 15) / 16;
             const int nblocks = g.B * tiles_x * tiles_y;
             constexpr int lds = 2 * C64_PATCH + 32768;

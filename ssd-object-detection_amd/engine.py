@@ -179,8 +179,9 @@ class SSDEngine:
         self.step_count = 0
         self.refresh_weights(cast=True)
 
-    def refresh_weights(self, cast=False):
-        """bf16 copy (if not already written by the optimizer kernel) + transposed copies for the data gradient."""
+    def refresh_weights(self, cast=False, tensors=None):
+        """bf16 copy (if not already written by the optimizer kernel) + transposed copies for the data gradient.
+        tensors=(t0, t1): only the copies of parameter tensors t0..t1-1 (the per-bucket optimizer step)."""
         if cast:
             ops.cast_bf16(self.param, self.param_bf16)
         if getattr(self, "_tr_desc", None) is None:         # {src, dst, Cout, k, Cin, Cout_pad} per transposed copy
@@ -194,7 +195,15 @@ class SSDEngine:
                 tiles = max(tiles, ((cpad + 31) // 32) * ((cin + 31) // 32) * k * k)
             self._tr_desc = torch.tensor(rows, dtype=torch.int64, device=self.device)
             self._tr_tiles = tiles
-        _lib.check(self.L.ssd_weight_transpose_batched(ops._ptr(self._tr_desc), self._tr_desc.shape[0], self._tr_tiles,
+            self._tr_tensor = [pt.index for pt, _ in pairs]      # ascending: trunk kernels, then head kernels
+        r0, r1 = 0, self._tr_desc.shape[0]
+        if tensors is not None:
+            inside = [r for r, t in enumerate(self._tr_tensor) if tensors[0] <= t < tensors[1]]
+            if not inside:
+                return
+            r0, r1 = inside[0], inside[-1] + 1
+            assert inside == list(range(r0, r1))
+        _lib.check(self.L.ssd_weight_transpose_batched(ops._ptr(self._tr_desc[r0:]), r1 - r0, self._tr_tiles,
                                                        ops._stream()))
 
     # ---------------------------------------------------------------- activations
@@ -275,10 +284,13 @@ class SSDEngine:
             main.wait_stream(side)
         return c["loc"], c["conf"]
 
-    def backward(self, dloc, dconf, on_ready=None):
+    def backward(self, dloc, dconf, on_ready=None, fused_adam=None):
         """Gradients of all parameters into self.grad (flat fp32) from d(loss)/d(loc), d(loss)/d(conf).
         on_ready([tensor indices]) is called right after the launches that complete those tensors' gradients (on the
         stream that runs them: an event recorded there covers them).
+        fused_adam = dict(lr, beta1, beta2, eps, clip): clip_by_norm + Adam + weight copies run per bucket of tensors
+        (opt_buckets) on the side stream as soon as the bucket's gradients exist and the last data gradient that reads
+        its transposed weights has been enqueued -- the optimizer disappears under the rest of the backward pass.
 
         The data-gradient chain (the critical path) runs on the current stream, every weight gradient on the side
         stream as soon as its input gradient exists: the split reductions and round tails of one overlap the MFMA
@@ -289,6 +301,19 @@ class SSDEngine:
         written = [False] * len(acts)
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.overlap_heads else None
+        opt_at = {}
+        if fused_adam is not None:
+            self.step_count += 1
+            t = self.step_count
+            hp = fused_adam
+            lr_t = hp["lr"] * math.sqrt(1.0 - hp["beta2"] ** t) / (1.0 - hp["beta1"] ** t)
+            opt_at = {node: (t0, t1) for t0, t1, node in self.opt_buckets()}
+
+        def opt_bucket(node):
+            """Called once the data gradient of `node` (None: of every head) is enqueued on the main stream."""
+            if node in opt_at:
+                t0, t1 = opt_at.pop(node)
+                on_side(lambda ws: self.adam_range(t0, t1, lr_t, hp["beta1"], hp["beta2"], hp["eps"], hp["clip"]), [])
 
         def on_side(fn, tensors):
             """Run fn (a weight-gradient launch) after everything enqueued so far on the main stream."""
@@ -305,24 +330,58 @@ class SSDEngine:
                 if on_ready:
                     on_ready(tensors)
 
-        # heads: weight gradients and their contribution to the feature-map gradients
+        # heads.  The two large levels (38x38, 19x19: ~1.1 ms of work) go to the side stream whole, data gradient first, so
+        # that the main stream can walk the small levels and the extras' data-gradient chain (a dozen launches that
+        # each fill a fraction of the chip) underneath them.  The accumulation order into a feature-map gradient is
+        # still "head first, trunk second": the trunk launch waits for the head's event.
+        big = [lvl for lvl, (ni, h, ch) in enumerate(self.fm) if side is not None and B * h * h >= 16384
+               and os.environ.get("SSD_BIG_HEADS_SIDE", "1") == "1"]
+        head_done = {}                                     # activation index -> event after the head's data gradient
+        packed = []
         for lvl, (ni, h, ch) in enumerate(self.fm):
             n = self.num_priors[lvl]
-            packed = ops.head_grad_pack(dloc, dconf, h * h, n, self.classes, self.head_npad[lvl], self.level_off[lvl],
-                                        out=c["packed"][lvl]).view(B, h, h, self.head_npad[lvl])
-            wt, bt = self.head_params[lvl]
-            on_side(lambda ws, a=acts[ni + 1], p=packed, wt=wt, bt=bt: ops.conv2d_bwd_weight(
-                a, p, wt.shape[0], 3, 1, 1, 1, dw=self.view(wt, self.grad), dbias=self.view(bt, self.grad), ws=ws),
-                [wt.index, bt.index])
-            ops.conv2d_bwd_data(packed, self.head_w_t[lvl], acts[ni + 1], acts[ni + 1].shape, 1, 1, 1,
-                                accumulate=False, out=gacts[ni + 1], ws=self._ws)
+            packed.append(ops.head_grad_pack(dloc, dconf, h * h, n, self.classes, self.head_npad[lvl],
+                                             self.level_off[lvl], out=c["packed"][lvl]).view(B, h, h, self.head_npad[lvl]))
+
+        def head_dgrad(lvl, ws):
+            ni = self.fm[lvl][0]
+            ops.conv2d_bwd_data(packed[lvl], self.head_w_t[lvl], acts[ni + 1], acts[ni + 1].shape, 1, 1, 1,
+                                accumulate=False, out=gacts[ni + 1], ws=ws)
             written[ni + 1] = True
+
+        def head_wgrad(lvl, ws):
+            ni = self.fm[lvl][0]
+            wt, bt = self.head_params[lvl]
+            ops.conv2d_bwd_weight(acts[ni + 1], packed[lvl], wt.shape[0], 3, 1, 1, 1, dw=self.view(wt, self.grad),
+                                  dbias=self.view(bt, self.grad), ws=ws)
+
+        if big:
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                for lvl in reversed(big):                  # 19x19 first: the trunk chain reaches it first
+                    head_dgrad(lvl, self._ws_side)
+                    done = torch.cuda.Event()
+                    done.record(side)
+                    head_done[self.fm[lvl][0] + 1] = done
+                for lvl in reversed(big):
+                    head_wgrad(lvl, self._ws_side)
+                    if on_ready:
+                        on_ready([t.index for t in self.head_params[lvl]])
+        for lvl in range(len(self.fm)):
+            if lvl in big:
+                continue
+            on_side(lambda ws, lvl=lvl: head_wgrad(lvl, ws), [t.index for t in self.head_params[lvl]])
+            head_dgrad(lvl, self._ws)
+        opt_bucket(None)
         # trunk, last layer first
         for i in range(len(self.nodes) - 1, -1, -1):
             nd = self.nodes[i]
             g_out = gacts[i + 1]
             assert written[i + 1]
             if nd["kind"] == "pool":
+                assert not written[i], "a pooled activation cannot also feed a head (the pool gradient overwrites)"
                 ops.maxpool2x2_bwd_argmax(c["pool_code"][i], g_out, acts[i].shape, out=gacts[i])
                 written[i] = True
                 continue
@@ -331,11 +390,16 @@ class SSDEngine:
                 a, go, nd["cout"], nd["k"], nd["stride"], nd["pt"], nd["pl"], dw=self.view(wt, self.grad),
                 dbias=self.view(bt, self.grad), ws=ws), [wt.index, bt.index])
             if i == 0:
+                opt_bucket(i)
                 continue                          # no gradient w.r.t. the image
             prev_is_relu_conv = self.nodes[i - 1]["kind"] == "conv"
+            if i in head_done:                    # a large head wrote gacts[i] on the side stream: accumulate after it
+                main.wait_event(head_done.pop(i))
             ops.conv2d_bwd_data(g_out, self.w_t[i], acts[i] if prev_is_relu_conv else None, acts[i].shape, nd["stride"],
                                 nd["pt"], nd["pl"], accumulate=written[i], out=gacts[i], ws=self._ws)
             written[i] = True
+            opt_bucket(i)
+        assert not opt_at
         if side is not None:
             main.wait_stream(side)
 
@@ -350,8 +414,8 @@ class SSDEngine:
         _lib.check(self.L.ssd_grad_apply_scale(ops._ptr(self.grad), self.n_flat, ops._ptr(self.block_tensor),
                                                ops._ptr(self.clip_scale), ops._stream()))
 
-    def clip_range_in_place(self, t0, t1, clip=0.01):
-        """clip_by_norm of tensors t0..t1-1 (a contiguous range of the flat gradient) in place, on the current stream."""
+    def _range_table(self, t0, t1):
+        """(first block, tensor->block offsets, block->tensor map), both relative to the range, for tensors t0..t1-1."""
         key = (t0, t1)
         if not hasattr(self, "_range_tables"):
             self._range_tables = {}
@@ -362,7 +426,44 @@ class SSDEngine:
             bt = (self.block_tensor[b0:int(self.tensor_block_off[t1].item())] - t0).contiguous()
             tab = (b0, tbo, bt)
             self._range_tables[key] = tab
-        b0, tbo, bt = tab
+        return tab
+
+    def opt_buckets(self, min_elems=2_000_000):
+        """Contiguous tensor ranges for the per-bucket optimizer step, in the order the backward pass completes them:
+        [(t0, t1, node)] -- node = lowest trunk node of the range (its data gradient is the last reader of the
+        range's transposed weights), None for the heads (all of them, first)."""
+        if getattr(self, "_opt_buckets", None) is None:
+            first_head = self.head_params[0][0].index
+            out = [(first_head, len(self.tensors), None)]
+            hi, acc = first_head, 0
+            conv_nodes = sorted(self.conv_params)
+            for i in reversed(conv_nodes):
+                wt, bt = self.conv_params[i]
+                acc += wt.numel + bt.numel
+                if acc >= min_elems or i == conv_nodes[0]:
+                    out.append((wt.index, hi, i))
+                    hi, acc = wt.index, 0
+            self._opt_buckets = out
+        return self._opt_buckets
+
+    def adam_range(self, t0, t1, lr_t, beta1, beta2, eps, clip):
+        """clip_by_norm + Adam + bf16 / transposed copies for parameter tensors t0..t1-1 on the current stream.
+        Per tensor the arithmetic is that of clip_scales() + adam() over the whole flat buffer, bit for bit."""
+        b0, tbo, bt = self._range_table(t0, t1)
+        start, n = b0 * self.block, bt.numel() * self.block
+        sl = slice(start, start + n)
+        _lib.check(self.L.ssd_grad_clip_scales(ops._ptr(self.grad[sl]), n, ops._ptr(tbo), t1 - t0, float(clip),
+                                               ops._ptr(self.sq_partial[b0:]), ops._ptr(self.clip_scale[t0:]),
+                                               ops._ptr(self.grad_norms[t0:]), ops._stream()))
+        _lib.check(self.L.ssd_adam_step(ops._ptr(self.param[sl]), ops._ptr(self.grad[sl]), ops._ptr(self.adam_m[sl]),
+                                        ops._ptr(self.adam_v[sl]), ops._ptr(self.param_bf16[sl]), n, ops._ptr(bt),
+                                        ops._ptr(self.clip_scale[t0:]), 1.0, float(lr_t), float(beta1), float(beta2),
+                                        float(eps), ops._stream()))
+        self.refresh_weights(tensors=(t0, t1))
+
+    def clip_range_in_place(self, t0, t1, clip=0.01):
+        """clip_by_norm of tensors t0..t1-1 (a contiguous range of the flat gradient) in place, on the current stream."""
+        b0, tbo, bt = self._range_table(t0, t1)
         start = b0 * self.block
         n = bt.numel() * self.block
         g = self.grad[start:start + n]

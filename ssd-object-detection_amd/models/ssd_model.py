@@ -66,6 +66,9 @@ class SSDObjectDetectionModel:
         self._slot_owner = None                      # optimizer object whose Adam moments the engine holds
         self._reducer = None
         self.last_info = None
+        self._targets_event = None
+        self._match_ws = ops.MatchWorkspace()
+        self.fused_optimizer = os.environ.get("SSD_FUSED_OPTIMIZER", "1") == "1"   # Adam per bucket inside backward
 
     # ------------------------------------------------------------------ accessors
     def get_prior_box(self):
@@ -98,6 +101,27 @@ class SSDObjectDetectionModel:
                         imgs, clss, boxes = [], [], []
 
         return _Batches()
+
+    def match_async(self, gt, out=None):
+        """Target assignment (A3-A5) for a packed ground-truth batch on the engine's side stream: it depends on nothing
+        the network computes, so it runs underneath the forward pass; _train_step waits for it before the loss.
+        gt = ops.pack_gt(...) tuple; out = optional (cls, loc, mask) buffers to reuse."""
+        B, A, dev = gt[2].numel() - 1, self._pset.A, self.device
+        if out is None:
+            out = (torch.empty((B, A), dtype=torch.int32, device=dev),
+                   torch.empty((B, A, 4), dtype=torch.float32, device=dev),
+                   torch.empty((B, A), dtype=torch.uint8, device=dev))
+        side = self._engine._side_stream() if self._engine.overlap_heads else None
+        if side is None:
+            return ops.match_encode(*gt, self._pset, self.cfg.thresh, out=out, ws=self._match_ws)
+        start = torch.cuda.Event()
+        start.record()                                 # everything that still reads `out` / gt is ahead of this point
+        with torch.cuda.stream(side):
+            side.wait_event(start)
+            ops.match_encode(*gt, self._pset, self.cfg.thresh, out=out, ws=self._match_ws)
+            self._targets_event = torch.cuda.Event()
+            self._targets_event.record(side)
+        return out
 
     def make_batch(self, images, cls_list, box_list):
         img = torch.from_numpy(np.stack(images, 0)).to(self.device, non_blocking=True)
@@ -153,30 +177,40 @@ class SSDObjectDetectionModel:
             blocks = [(t.numel + eng.block - 1) // eng.block for t in eng.tensors]
             self._reducer = GradReducer(eng.grad, [t.offset for t in eng.tensors], blocks, eng.block,
                                         eng.clip_range_in_place)
+        fused = single and isinstance(ssd_optimizer, _opt.Adam) and self.fused_optimizer
+        if fused:                                      # the optimizer runs per bucket inside the backward pass
+            self._adopt_slots(ssd_optimizer)
+            eng.step_count = ssd_optimizer.iterations
+            lr = ssd_optimizer.lr()
+            fused_adam = dict(lr=lr, beta1=ssd_optimizer.beta_1, beta2=ssd_optimizer.beta_2,
+                              eps=ssd_optimizer.epsilon, clip=0.01)          # tf.clip_by_norm(x, 0.01), reference :249
         for i in range(0, batch_size, batch_step):
             if image.dtype == torch.bfloat16:          # already prepared on the device (make_batch_raw)
                 x = image[i:i + batch_step]
             else:
                 x = ops.image_prep(image[i:i + batch_step].contiguous(), normalize=False)
             pred_loc, pred_conf = eng.forward(x)
+            if self._targets_event is not None:        # targets assigned on the side stream (match_async)
+                torch.cuda.current_stream().wait_event(self._targets_event)
+                self._targets_event = None
             _, info = self._ssd_loss((gt_cls[i:i + batch_step], gt_bbox[i:i + batch_step], gt_mask[i:i + batch_step]),
                                      (pred_loc, pred_conf))
             if overlap:
                 self._reducer.begin()
                 eng.backward(info["dloc"], info["dconf"], on_ready=self._reducer.tensor_ready)
                 self._reducer.finish()                 # clipped per bucket, summed over ranks (RCCL over xGMI)
+            elif fused:
+                eng.backward(info["dloc"], info["dconf"], fused_adam=fused_adam)
             else:
                 eng.backward(info["dloc"], info["dconf"])
                 eng.clip_scales(0.01)                  # tf.clip_by_norm(x, 0.01) per tensor, reference :249
                 if not single:
                     eng.accumulate_clipped(first=(n_micro == 0))
             n_micro += 1
-        if self._slot_owner is _RESTORED:             # moments came from a checkpoint: the first optimizer adopts them
-            self._slot_owner = ssd_optimizer
-        elif self._slot_owner is not ssd_optimizer:   # Keras keeps separate slots per optimizer (warm-up vs train)
-            eng.adam_m.zero_()
-            eng.adam_v.zero_()
-            self._slot_owner = ssd_optimizer
+        if fused:
+            ssd_optimizer.iterations += 1
+            return self._finish_step(info, lr, pred_conf, pred_loc)
+        self._adopt_slots(ssd_optimizer)
         lr = ssd_optimizer.lr()
         if single:
             grad, gscale, use_clip = eng.grad, 1.0, True
@@ -193,6 +227,18 @@ class SSDObjectDetectionModel:
             eng.step_count = ssd_optimizer.iterations
             eng.adam(lr, grad, gscale, use_clip, ssd_optimizer.beta_1, ssd_optimizer.beta_2, ssd_optimizer.epsilon)
         ssd_optimizer.iterations += 1
+        return self._finish_step(info, lr, pred_conf, pred_loc)
+
+    def _adopt_slots(self, ssd_optimizer):
+        eng = self._engine
+        if self._slot_owner is _RESTORED:             # moments came from a checkpoint: the first optimizer adopts them
+            self._slot_owner = ssd_optimizer
+        elif self._slot_owner is not ssd_optimizer:   # Keras keeps separate slots per optimizer (warm-up vs train)
+            eng.adam_m.zero_()
+            eng.adam_v.zero_()
+            self._slot_owner = ssd_optimizer
+
+    def _finish_step(self, info, lr, pred_conf, pred_loc):
         self._last_raw = info["raw"]                  # device f32[8] row for the sync-free scalar log (N4)
         info = {k: v for k, v in info.items() if k in ("cls loss pos", "cls loss neg", "loc loss", "status")}
         info["lr"] = lr

@@ -165,3 +165,46 @@ def test_scalars_are_logged_without_per_step_syncs(tmp_path):
     got = read_scalars(os.path.join(m_async.get_log_dir(), "scalars.jsonl"))
     assert set(got) == {"train/" + t for t in TAGS} and all(len(v) == 5 for v in got.values())
     assert torch.equal(m_sync.get_engine().param, m_async.get_engine().param)
+
+
+def test_bucketed_optimizer_and_async_targets_are_bitwise_neutral(tmp_path):
+    """Adam per bucket inside the backward pass (engine.backward(fused_adam=...)) and target assignment on the side stream
+    (match_async) change when kernels run, not what they compute: weights, both moments, the bf16 and transposed copies
+    after three steps equal those of the plain sequence clip_scales() -> adam() with targets assigned up front."""
+    from ssd_object_detection_amd import ops, optimizers
+    from ssd_object_detection_amd.data_loaders.synthetic import synth_batch_gt
+    from ssd_object_detection_amd.models import SSDObjectDetectionModel
+    B = 8
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    imgs = [(torch.rand((B, 300, 300, 3), generator=gen, device="cuda") - 0.5) * 2 for _ in range(2)]
+    gts = [ops.pack_gt(*reversed(synth_batch_gt(i * B, B))) for i in range(2)]
+
+    def run(fused, async_targets):
+        model = SSDObjectDetectionModel(classes=80, log_dir=str(tmp_path), timestamp_dir=False)
+        model.fused_optimizer = fused
+        opt = optimizers.Adam(optimizers.ExponentialDecay(1e-3, 100, 0.9))
+        out, losses = None, []
+        for step in range(3):
+            gt = gts[step % 2]
+            if async_targets:
+                out = model.match_async(gt, out=out)
+            else:
+                out = ops.match_encode(*gt, model._pset, 0.5)
+            _, _, info = model._train_step(imgs[step % 2], *out, opt)
+            losses.append(info["loc loss"].clone())
+        torch.cuda.synchronize()
+        return model.get_engine(), losses
+
+    a, la = run(False, False)
+    b, lb = run(True, True)
+    assert a.step_count == b.step_count == 3
+    for name in ("param", "adam_m", "adam_v", "param_bf16", "clip_scale", "grad_norms"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    for i in a.w_t:
+        assert torch.equal(a.w_t[i], b.w_t[i]), i
+    for x, y in zip(a.head_w_t, b.head_w_t):
+        assert torch.equal(x, y)
+    assert all(torch.equal(x, y) for x, y in zip(la, lb))
+    assert len(b.opt_buckets()) >= 4 and b.opt_buckets()[0][2] is None
+    covered = sorted(t for t0, t1, _ in b.opt_buckets() for t in range(t0, t1))
+    assert covered == list(range(len(b.tensors)))

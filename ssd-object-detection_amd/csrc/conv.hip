@@ -1459,7 +1459,17 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
             }
         }
     };
-    if ((int)blockIdx.x < nblocks) issue_patch(blockIdx.x, 0);
+    // XCD-aware order: workgroup i runs on XCD i % 8; give every XCD one contiguous range of blocks and let its workgroups
+    // walk it side by side, so that the halo rows/columns shared by neighbouring blocks meet in that XCD's L2
+    const bool xcd_order = (gridDim.x & 7) == 0 && !(g.ablate & 64);
+    const int per_xcd = (nblocks + 7) >> 3, slots = gridDim.x >> 3;
+    auto block_of = [&](int i) {                            // the i-th block of this workgroup, -1 = done
+        if (!xcd_order) { const int t = blockIdx.x + i * gridDim.x; return t < nblocks ? t : -1; }
+        const int lin = i * slots + ((int)blockIdx.x >> 3);
+        const int t = ((int)blockIdx.x & 7) * per_xcd + lin;
+        return (lin < per_xcd && t < nblocks) ? t : -1;
+    };
+    if (block_of(0) >= 0) issue_patch(block_of(0), 0);
 
     const int frow = lane & 15, fk = lane >> 4;
     bf16x8_t fw[2][9][2];                                   // as in k_conv3x3_c64
@@ -1478,7 +1488,7 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
     const int xbase = (4 * wave_m * PATCH_W + frow) * C64_PITCH + fk * 16;
 
     int it = 0, prev_st = 0;
-    for (int t = blockIdx.x; t < nblocks; t += gridDim.x, ++it) {
+    for (int t = block_of(0); t >= 0; t = block_of(++it)) {
         const int cur = it & 1;
         if (prev_st >= 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         else if (prev_st == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
@@ -1486,12 +1496,29 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
         else if (prev_st == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
-        if (t + (int)gridDim.x < nblocks && !(g.ablate & 1)) issue_patch(t + gridDim.x, cur ^ 1);
         int r = t;
         const int tx = r % tiles_x; r /= tiles_x;
         const int ty = r % tiles_y;
         const int b = r / tiles_y;
         const int y0 = ty * C64B_ROWS, x0 = tx * 16;
+        // data gradient: the ReLU mask (the forward activation at the output position) is fetched NOW, ahead of the next
+        // patch, and is in registers long before the epilogue needs it -- fetched there, every block paid a full memory
+        // round trip with the matrix cores idle (300 us of the 630 us this kernel took)
+        uint4 mk[4];
+        int mk_m[4];
+        const bool premask = EPI == EPI_DGRAD && ep.mask_src != nullptr && !(g.ablate & 128);
+        if constexpr (EPI == EPI_DGRAD) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = i * 256 + tid, row = idx >> 3, ch = idx & 7;
+                const int y = y0 + (row >> 4), xx = x0 + (row & 15);
+                mk_m[i] = (y < g.Ho && xx < g.Wo) ? (b * g.Ho + y) * g.Wo + xx : -1;
+                mk[i] = make_uint4(0, 0, 0, 0);
+                if (premask && mk_m[i] >= 0) mk[i] = *reinterpret_cast<const uint4*>(ep.mask_src + (long long)mk_m[i] * ep.ldo + ch * 8);
+            }
+        }
+        const int tnext = block_of(it + 1);
+        if (tnext >= 0 && !(g.ablate & 1)) issue_patch(tnext, cur ^ 1);
         const int pb = cur * C64B_PATCH + xbase;
         f32x4_t acc[2][4];
 #pragma unroll
@@ -1536,7 +1563,39 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
             const int gy = (y0 >> 1) + py, gx = (x0 >> 1) + px;
             return (gy < ep.pool_h && gx < ep.pool_w) ? ((long long)b * ep.pool_h + gy) * ep.pool_w + gx : -1;
         };
-        staged_epilogue<EPI, 128, 64, 2, 4, 256>(acc, smem + C64B_STAGE, g, ep, 0, wave_m * 64, wave_n * 32, tid, row_to_m, pool_index);
+        if (premask) {
+            if constexpr (EPI == EPI_DGRAD) {               // staged_epilogue's data-gradient path with the mask already here
+                char* st = smem + C64B_STAGE;
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int col = wave_n * 32 + c * 16 + (lane >> 4) * 4;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const int row = wave_m * 64 + p * 16 + (lane & 15);
+                        *reinterpret_cast<uint2*>(st + row * 128 + ((((col >> 3) ^ row) & 7) << 4) + (col & 4) * 2) =
+                            make_uint2((unsigned)f2bf(acc[c][p][0]) | ((unsigned)f2bf(acc[c][p][1]) << 16),
+                                       (unsigned)f2bf(acc[c][p][2]) | ((unsigned)f2bf(acc[c][p][3]) << 16));
+                    }
+                }
+                __syncthreads();
+                auto gate = [](unsigned val, unsigned m2) {
+                    if (!(__uint_as_float(m2 << 16) > 0.f)) val &= 0xffff0000u;
+                    if (!(__uint_as_float(m2 & 0xffff0000u) > 0.f)) val &= 0x0000ffffu;
+                    return val;
+                };
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int idx = i * 256 + tid, row = idx >> 3, ch = idx & 7;
+                    if (mk_m[i] < 0) continue;
+                    uint4 v = *reinterpret_cast<const uint4*>(st + row * 128 + (((ch ^ row) & 7) << 4));
+                    v.x = gate(v.x, mk[i].x); v.y = gate(v.y, mk[i].y); v.z = gate(v.z, mk[i].z); v.w = gate(v.w, mk[i].w);
+                    *reinterpret_cast<uint4*>(ep.out + (long long)mk_m[i] * ep.ldo + ch * 8) = v;
+                }
+            }
+        } else {
+            staged_epilogue<EPI, 128, 64, 2, 4, 256>(acc, smem + C64B_STAGE, g, ep, 0, wave_m * 64, wave_n * 32, tid, row_to_m, pool_index);
+        }
         // store instructions of that epilogue with at least one active lane (its loop: iteration i, wave w covers the
         // 8 pixels x = 8 (w & 1) .. +7 of block row 2 i + (w >> 1)): a lower bound of what this wave issued after the DMA
         prev_st = 0;

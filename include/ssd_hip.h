@@ -169,7 +169,10 @@ int ssd_conv2d_fwd(const void* x, const void* w, const float* bias, void* y, int
                    size_t ws_bytes, void* stream);
 /* Conv2D + bias + ReLU followed by MaxPool2D 2x2 / stride 2 (models/ssd_model.py:77-84: block1_conv2 -> block1_pool etc.):
  * y as ssd_conv2d_fwd, y_pool [B,Hp,Wp,Cout] and pool_code as ssd_maxpool2x2_fwd_argmax of y.  Layers served by a
- * 16x16-block kernel pool the tile they already hold on chip; otherwise two launches.  Cout % 8 == 0. */
+ * 16-wide block kernel pool the tile they already hold on chip; otherwise two launches.  Cout % 8 == 0.
+ * y may be NULL when nothing but the pooling reads the full-resolution map (true for every pooled layer of the SSD300
+ * trunk: the backward pass needs the pooled map and the winner codes only): the fused kernels then skip that store
+ * (half of block1_conv2's traffic); a layer shape they do not serve returns SSD_ERR_VALUE before anything is launched. */
 int ssd_conv2d_fwd_pool(const void* x, const void* w, const float* bias, void* y, void* y_pool, void* pool_code, int B, int H,
                         int W, int Cin, int Cout, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int relu, int Hp,
                         int Wp, void* ws, size_t ws_bytes, void* stream);

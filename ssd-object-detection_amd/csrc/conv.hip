@@ -291,8 +291,10 @@ __device__ __forceinline__ void staged_epilogue(f32x4_t (&acc)[CT][PT], char* sm
         }
     } else {
         constexpr int ITER = BM * CPR / NT;
+        // forward with fused pooling and no consumer of the full-resolution map (out == nullptr): only the pooled map leaves
+        const bool store_full = EPI != EPI_FWD || ep.out != nullptr;
 #pragma unroll 4
-        for (int it = 0; it < ITER; ++it) {
+        for (int it = 0; it < (store_full ? ITER : 0); ++it) {
             const int idx = it * NT + tid;
             const int row = idx / CPR, ch = idx - row * CPR;
             const int n = n0 + ch * 8;
@@ -1403,6 +1405,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_c64(const bf16_raw* __restrict_
         prev_st = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) prev_st += (y0 + 4 * i + (wave >> 1) < g.Ho && x0 + 8 * (wave & 1) < g.Wo) ? 1 : 0;
+        if (EPI == EPI_FWD && !ep.out) prev_st = 0;          // pool-only: no full-resolution stores to leave in flight
     }
 }
 
@@ -1601,6 +1604,7 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
         prev_st = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) prev_st += (y0 + 2 * i + (wave >> 1) < g.Ho && x0 + 8 * (wave & 1) < g.Wo) ? 1 : 0;
+        if (EPI == EPI_FWD && !ep.out) prev_st = 0;          // pool-only: no full-resolution stores to leave in flight
     }
 }
 
@@ -3016,6 +3020,7 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
         if (knob("SSD_CONV_C64", 2) && igemm_variant() >= 1 && g.KH == 3 && g.KW == 3 && g.mul == 1 && g.div == 1 && g.pad_t == 1 &&
             g.pad_l == 1 && g.C == 64 && g.N == 64 && g.ldw == 576 && g.H == g.Ho && g.W == g.Wo && g.H >= 16 && g.W >= 16 &&
             !ep.accumulate && (ep.ldo & 7) == 0 && (long long)g.B * g.H * g.W * 64 < (1ll << 31) - 16) {
+            if (EPI == EPI_FWD && !ep.out && !(pooled && ep.pool_out)) return SSD_ERR_VALUE;
             if (knob("SSD_CONV_C64", 2) >= 2) {             // 8 x 16 blocks, two workgroups per CU
                 const int tiles_x = (g.Wo + 15) / 16, tiles_y = (g.Ho + C64B_ROWS - 1) / C64B_ROWS;
                 const int nblocks = g.B * tiles_x * tiles_y;
@@ -3065,12 +3070,15 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
                 const unsigned ntn_ = (unsigned)((g.N + BN_ - 1) / BN_);                                            \
                 hipLaunchKernelGGL(kern_, dim3(8 * ntn_ * ((gxx + 7) / 8)), dim3(512), lds_, s, xp, wp, g, ep, tiles_x, tiles_y, (int)gxx); \
             } while (0)
+            const bool can_pool = pooled && ep.pool_out && !flat && (g.N & 7) == 0 && (ep.ldo & 7) == 0 && !(g.ablate & 8);
+            if (EPI == EPI_FWD && !ep.out && !can_pool) return SSD_ERR_VALUE;
             if (g.N <= 64) { if (flat) SSD_LAUNCH_P32(64, true); else SSD_LAUNCH_P32(64, false); }
             else { if (flat) SSD_LAUNCH_P32(128, true); else SSD_LAUNCH_P32(128, false); }
 #undef SSD_LAUNCH_P32
-            if (pooled && ep.pool_out && !flat && (g.N & 7) == 0 && (ep.ldo & 7) == 0 && !(g.ablate & 8)) *pooled = true;
+            if (can_pool) *pooled = true;
             return ssd_launch_status();
         }
+        if (EPI == EPI_FWD && !ep.out) return SSD_ERR_VALUE;     // pool-only needs a pooling kernel
         if (g.N <= 64) {
             const size_t lds = 2 * 64 * 128 + PATCH_BYTES;
             auto kern = k_conv3x3_patch<64, EPI>;
@@ -3086,6 +3094,7 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
         }
         return ssd_launch_status();
     }
+    if (EPI == EPI_FWD && !ep.out) return SSD_ERR_VALUE;         // pool-only needs a pooling kernel
     if (igemm_variant() >= 1) {
         // tile choice: the CU ingests ~28 B/clk from L2, so MACs per staged byte decide the ceiling: prefer the
         // largest tile that still gives every CU work (>= ~2 workgroups per CU), SSD_CONV_TILE overrides (testing)
@@ -3228,12 +3237,15 @@ int ssd_conv2d_fwd(const void* x, const void* w, const float* bias, void* y, int
 int ssd_conv2d_fwd_pool(const void* x, const void* w, const float* bias, void* y, void* y_pool, void* pool_code, int B, int H,
                         int W, int Cin, int Cout, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int relu, int Hp,
                         int Wp, void* ws, size_t ws_bytes, void* stream) {
-    if (!x || !w || !y || !y_pool || !pool_code || !geom_ok(B, H, W, Cin, Ho, Wo, Cout, ksize) || stride <= 0 || Cout % 8)
+    if (!x || !w || !y_pool || !pool_code || !geom_ok(B, H, W, Cin, Ho, Wo, Cout, ksize) || stride <= 0 || Cout % 8)
         return SSD_ERR_VALUE;
+    // y == NULL: the caller has no use for the full-resolution map (nothing but the pooling reads it): served only by the
+    // kernels that pool in their epilogue, SSD_ERR_VALUE (before anything is launched) for any other layer shape
     if ((Hp != Ho / 2 && Hp != (Ho + 1) / 2) || (Wp != Wo / 2 && Wp != (Wo + 1) / 2) || Hp <= 0 || Wp <= 0) return SSD_ERR_VALUE;
     const ConvGeom g = make_geom(B, H, W, Cin, Ho, Wo, Cout, ksize, ksize, stride, 1, pad_t, pad_l);
     Epilogue ep = {};
     ep.bias = bias; ep.relu = relu; ep.out = static_cast<bf16_raw*>(y); ep.ldo = Cout;
+    if (!y && !knob("SSD_CONV_POOL_FUSE", 1)) return SSD_ERR_VALUE;
     if (knob("SSD_CONV_POOL_FUSE", 1)) {
         ep.pool_out = static_cast<bf16_raw*>(y_pool); ep.pool_code = static_cast<unsigned*>(pool_code); ep.pool_h = Hp; ep.pool_w = Wp;
     }

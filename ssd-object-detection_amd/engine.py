@@ -68,6 +68,8 @@ class SSDEngine:
         self._side = None
         self.overlap_heads = os.environ.get("SSD_OVERLAP_HEADS", "1") != "0" and self.device.type == "cuda"
         self.step_count = 0
+        self.skip_fullres = os.environ.get("SSD_SKIP_FULLRES", "1") == "1"   # pooled convs store the pooled map only
+        self.pool_only = {}                    # node -> whether a pool-only kernel serves it (learned at the first call)
 
     # ---------------------------------------------------------------- static planning
     def _plan_shapes(self):
@@ -261,9 +263,20 @@ class SSDEngine:
                 wt, bt = self.conv_params[i]
                 nxt = self.nodes[i + 1] if i + 1 < len(self.nodes) else None
                 if nxt is not None and nxt["kind"] == "pool":      # conv + the pooling behind it in one call
-                    ops.conv2d_fwd_pool(acts[i], self.view(wt, self.param_bf16), self.view(bt, self.param), nd["stride"],
-                                        nd["pt"], nd["pl"], nd["hout"], nd["hout"], True, nxt["hout"] * 2 != nxt["hin"],
-                                        out=acts[i + 1], pool_out=acts[i + 2], code=c["pool_code"][i + 1], ws=self._ws)
+                    # nothing but the pooling reads this conv's full-resolution output (the backward pass works from the
+                    # pooled map and the winner codes): ask for the pooled map only, where a fused kernel serves the layer
+                    pool_only = self.pool_only.get(i, self.skip_fullres)
+                    args = (acts[i], self.view(wt, self.param_bf16), self.view(bt, self.param), nd["stride"], nd["pt"],
+                            nd["pl"], nd["hout"], nd["hout"], True, nxt["hout"] * 2 != nxt["hin"])
+                    kw = dict(out=acts[i + 1], pool_out=acts[i + 2], code=c["pool_code"][i + 1], ws=self._ws)
+                    if pool_only:
+                        try:
+                            ops.conv2d_fwd_pool(*args, pool_only=True, **kw)
+                        except ValueError:            # SSD_ERR_VALUE: no pooling kernel for this shape, nothing launched
+                            pool_only = False
+                    self.pool_only[i] = pool_only
+                    if not pool_only:
+                        ops.conv2d_fwd_pool(*args, **kw)
                 else:
                     ops.conv2d_fwd(acts[i], self.view(wt, self.param_bf16), self.view(bt, self.param), nd["stride"],
                                    nd["pt"], nd["pl"], nd["hout"], nd["hout"], True, out=acts[i + 1], ws=self._ws)

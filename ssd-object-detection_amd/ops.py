@@ -265,14 +265,19 @@ def conv2d_fwd(x, w, bias, stride, pad_t, pad_l, Ho, Wo, relu, out=None, ws=None
     return out
 
 
-def conv2d_fwd_pool(x, w, bias, stride, pad_t, pad_l, Ho, Wo, relu, same, out=None, pool_out=None, code=None, ws=None):
-    """conv2d_fwd followed by maxpool2x2_fwd_argmax of its output, fused on chip where the kernel allows."""
+def conv2d_fwd_pool(x, w, bias, stride, pad_t, pad_l, Ho, Wo, relu, same, out=None, pool_out=None, code=None, ws=None,
+                    pool_only=False):
+    """conv2d_fwd followed by maxpool2x2_fwd_argmax of its output, fused on chip where the kernel allows.
+    pool_only=True: the full-resolution map is not stored (returned as None); raises ValueError (SSD_ERR_VALUE) for a layer
+    shape that no pooling kernel serves (nothing is launched then)."""
     L = _lib.lib()
     _bf(x); _bf(w)
     B, H, W, Cin = x.shape
     Cout, k = w.shape[0], w.shape[1]
     Hp, Wp = ((Ho + 1) // 2, (Wo + 1) // 2) if same else (Ho // 2, Wo // 2)
-    if out is None:
+    if pool_only:
+        out = None
+    elif out is None:
         out = torch.empty((B, Ho, Wo, Cout), dtype=torch.bfloat16, device=x.device)
     if pool_out is None:
         pool_out = torch.empty((B, Hp, Wp, Cout), dtype=torch.bfloat16, device=x.device)

@@ -270,6 +270,14 @@ def test_conv_fwd_pool_fused(ops, case):
     y_ref = ops.conv2d_fwd(x, w, bias, 1, 1, 1, H, H, True)
     yp_ref, code_ref = ops.maxpool2x2_fwd_argmax(y_ref, same=same)
     assert torch.equal(y, y_ref) and torch.equal(yp, yp_ref) and torch.equal(code, code_ref)
+    # pool-only form (y == NULL in the C ABI): same pooled map and codes, no full-resolution store; a layer shape that no
+    # pooling kernel serves is refused before anything is launched
+    try:
+        none, yp2, code2 = ops.conv2d_fwd_pool(x, w, bias, 1, 1, 1, H, H, True, same, pool_only=True)
+    except ValueError:
+        assert Cin % 64 != 0 or H < 16
+    else:
+        assert none is None and torch.equal(yp2, yp_ref) and torch.equal(code2, code_ref)
 
 
 def test_image_prep(ops):

@@ -334,6 +334,40 @@ __device__ __forceinline__ void staged_epilogue(f32x4_t (&acc)[CT][PT], char* sm
                     const int n = n0 + ch * 8;
                     const long long po = pool_index(py, px);
                     if (po < 0 || n >= g.N) continue;
+                    if (ep.relu) {
+                        // after ReLU every candidate is >= +0 (v_max_f32 returns +0 for max(-0, +0)), so bf16 bit patterns
+                        // order like the values: packed 16-bit integer max / compare, two channels per instruction
+                        // (the float form below cost 25 % of block1_conv2's forward time)
+                        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                        uint4 cand[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int row = (2 * py + (q >> 1)) * 16 + 2 * px + (q & 1);
+                            cand[q] = make_uint4(0, 0, 0, 0);      // a position outside the map never wins: 0 only ties with 0 = dead
+                            if (row_to_m(row) >= 0) cand[q] = *reinterpret_cast<const uint4*>(smem + row * (BN * 2) + (((ch ^ row) & (CPR - 1)) << 4));
+                        }
+                        unsigned o4[4], cw = 0;
+                        const us2 one = {1, 1}, four = {4, 4};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const unsigned w0 = (&cand[0].x)[k], w1 = (&cand[1].x)[k], w2 = (&cand[2].x)[k], w3 = (&cand[3].x)[k];
+                            const us2 a = __builtin_bit_cast(us2, w0), b2 = __builtin_bit_cast(us2, w1), c2 = __builtin_bit_cast(us2, w2),
+                                      d2 = __builtin_bit_cast(us2, w3);
+                            const us2 m = __builtin_elementwise_max(__builtin_elementwise_max(a, b2), __builtin_elementwise_max(c2, d2));
+                            const us2 ne0 = __builtin_elementwise_min((us2)(a ^ m), one), ne1 = __builtin_elementwise_min((us2)(b2 ^ m), one),
+                                      ne2 = __builtin_elementwise_min((us2)(c2 ^ m), one);
+                            const us2 t = ne1 * ne2 + ne1;                   // ne1 (1 + ne2)
+                            const us2 first = ne0 * t + ne0;                 // index of the first candidate equal to the max
+                            const us2 alive = __builtin_elementwise_min(m, one);
+                            const us2 code = alive * (us2)(first - four) + four;   // 4 = no winner (max is 0)
+                            o4[k] = __builtin_bit_cast(unsigned, m);
+                            const unsigned cu = __builtin_bit_cast(unsigned, code);
+                            cw |= ((cu & 0xfu) | ((cu >> 12) & 0xf0u)) << (8 * k);
+                        }
+                        *reinterpret_cast<uint4*>(ep.pool_out + po * g.N + n) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+                        ep.pool_code[po * (g.N >> 3) + (n >> 3)] = cw;
+                        continue;
+                    }
                     float best[8];
                     unsigned pos[8];
 #pragma unroll
@@ -1493,7 +1527,11 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
     int it = 0, prev_st = 0;
     for (int t = block_of(0); t >= 0; t = block_of(++it)) {
         const int cur = it & 1;
-        if (prev_st >= 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        // this block's patch (issued one block ago) is older than the epilogue stores issued since: wait for all but those
+        // (prev_st = wave-uniform lower bound of the store instructions the previous epilogue issued)
+        if (prev_st >= 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else if (prev_st == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+        else if (prev_st == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         else if (prev_st == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
         else if (prev_st == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
         else if (prev_st == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
@@ -1604,7 +1642,9 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
         prev_st = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) prev_st += (y0 + 2 * i + (wave >> 1) < g.Ho && x0 + 8 * (wave & 1) < g.Wo) ? 1 : 0;
-        if (EPI == EPI_FWD && !ep.out) prev_st = 0;          // pool-only: no full-resolution stores to leave in flight
+        if (EPI == EPI_FWD && !ep.out) prev_st = 0;          // pool-only: no full-resolution stores
+        // fused pooling: wave w stores pooled row (y0 >> 1) + w, columns (x0 >> 1) .. + 7 (pooled map, then the codes)
+        if (EPI == EPI_FWD && ep.pool_out && (y0 >> 1) + wave < ep.pool_h && (x0 >> 1) < ep.pool_w) prev_st += 2;
     }
 }
 

@@ -18,6 +18,10 @@ if mode == "fwd":
     w = (torch.randn((Cout, k, k, Cin), device="cuda") * 0.05).bfloat16(); b = torch.zeros(Cout, device="cuda")
     y = ops.conv2d_fwd(x, w, b, 1, pt, pt, Ho, Ho, True)
     run = lambda: ops.conv2d_fwd(x, w, b, 1, pt, pt, Ho, Ho, True, out=y)
+elif mode == "fwdpool":                                  # conv + fused 2x2 pooling, pooled map only
+    w = (torch.randn((Cout, k, k, Cin), device="cuda") * 0.05).bfloat16(); b = torch.zeros(Cout, device="cuda")
+    _, yp, code = ops.conv2d_fwd_pool(x, w, b, 1, pt, pt, Ho, Ho, True, Ho % 2 == 1, pool_only=True)
+    run = lambda: ops.conv2d_fwd_pool(x, w, b, 1, pt, pt, Ho, Ho, True, Ho % 2 == 1, pool_out=yp, code=code, pool_only=True)
 elif mode == "head":
     per_cell = Cout // 85
     w = (torch.randn((Cout, 3, 3, Cin), device="cuda") * 0.05).bfloat16(); b = torch.zeros(Cout, device="cuda")

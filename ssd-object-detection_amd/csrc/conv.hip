@@ -70,6 +70,7 @@ struct ConvGeom {
     int ldw;                                 // weight row stride (elements) = KH*KW*C
     int cpt;                                 // chunks per tap = C/8
     FastDiv d_hw, d_w;                       // divide by Ho*Wo and by Wo
+    FastDiv d_h1;                            // divide by H + 1 (row strip of k_conv3x3_patch32)
     // stride-2 data gradient: destination pixels are enumerated parity class by parity class (py,px), each class
     // padded to whole tiles, so that a tile has ONE parity and the taps that cannot hit it are skipped outright
     int s2;                                  // 1: parity-class enumeration active (div == 2, cpt % 8 == 0)
@@ -1143,7 +1144,7 @@ constexpr int P32_PATCH = 32 * 1024;                       // 324 px x 96 B = 31
 
 template <int BN, int EPI, bool FLAT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_conv3x3_patch32(
-    const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ w, ConvGeom g, Epilogue ep, int tiles_x, int tiles_y, int nblocks) {
+    const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ w, ConvGeom g, Epilogue ep, int tiles_x, int tiles_y, int nblocks, int rowflat) {
     constexpr int CT = BN / 32;
     constexpr int PT = 4;
     constexpr int WBYTES = BN * 64;                          // weight slice of one tap
@@ -1175,10 +1176,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     } else {
         int t = pblock;
         const int tx = t % tiles_x; t /= tiles_x;
-        const int ty = t % tiles_y;
-        b = t / tiles_y;
-        y0 = ty * 16; x0 = tx * 16;
+        x0 = tx * 16;
+        if (rowflat) { y0 = t * 16; }                       // row of the strip of all images (below), not of one image
+        else { const int ty = t % tiles_y; b = t / tiles_y; y0 = ty * 16; }
     }
+    // rowflat (wide maps whose height is not a multiple of 16): the rows of all images form one strip, images separated
+    // by ONE zero row, and a block is 16 consecutive strip rows x 16 columns -- it may straddle two images, the shared
+    // zero row is the bottom padding of one and the top padding of the other.  75 rows per image cost 76 instead of 80.
+    // block row r (-1 .. 16 for the halo) -> row index into [B * H], -1 = padding / outside
+    auto image_row = [&](int r) {
+        if (!rowflat) { const int y = y0 + r; return (unsigned)y < (unsigned)g.H ? b * g.H + y : -1; }
+        const int R = y0 + r;
+        if (R < 0) return -1;
+        const int bb = fdiv(R, g.d_h1), yy = R - bb * (g.H + 1);
+        return (bb < g.B && yy < g.H) ? bb * g.H + yy : -1;
+    };
     // flat position -> source pixel (element offset / C) or -1
     auto flat_pixel = [&](int f) {
         if (f < 0) return -1;
@@ -1202,8 +1214,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             pix = pp < 256 + 2 * (Q + 1) ? flat_pixel(f0 - (Q + 1) + pp) : -1;
         } else {
             const int py = pp / PATCH_W, px = pp - py * PATCH_W;
-            const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-            pix = (pp < PATCH_PIX && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W) ? (b * g.H + iy) * g.W + ix : -1;
+            const int ix = x0 - 1 + px;
+            const int ir = pp < PATCH_PIX ? image_row(py - 1) : -1;
+            pix = (ir >= 0 && (unsigned)ix < (unsigned)g.W) ? ir * g.W + ix : -1;
         }
         pvo[j] = (sl < 4 && pix >= 0) ? ((unsigned)pix * (unsigned)g.C + (unsigned)(sl * 8)) * 2u : OOB;
     }
@@ -1279,11 +1292,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (staged_ok<EPI>(g, ep) && !(g.ablate & 8)) {          // tile image [256 block pixels][BN] in the (now idle) patch buffers
         auto row_to_m = [&](int row) {
             if (flat) return flat_pixel(f0 + row);
-            const int y = y0 + (row >> 4), xx = x0 + (row & 15);
-            return (y < g.Ho && xx < g.Wo) ? (b * g.Ho + y) * g.Wo + xx : -1;
+            const int ir = image_row(row >> 4), xx = x0 + (row & 15);
+            return (ir >= 0 && xx < g.Wo) ? ir * g.Wo + xx : -1;
         };
         auto pool_index = [&](int py, int px) -> long long {
-            if (flat) return -1;
+            if (flat || rowflat) return -1;
             const int gy = (y0 >> 1) + py, gx = (x0 >> 1) + px;
             return (gy < ep.pool_h && gx < ep.pool_w) ? ((long long)b * ep.pool_h + gy) * ep.pool_w + gx : -1;
         };
@@ -1296,8 +1309,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if (flat) {
             mrow[p] = flat_pixel(f0 + (4 * wave_m + p) * 16 + (lane & 15));
         } else {
-            const int y = y0 + 4 * wave_m + p, xx = x0 + (lane & 15);
-            mrow[p] = (y < g.Ho && xx < g.Wo) ? (b * g.Ho + y) * g.Wo + xx : -1;
+            const int ir = image_row(4 * wave_m + p), xx = x0 + (lane & 15);
+            mrow[p] = (ir >= 0 && xx < g.Wo) ? ir * g.Wo + xx : -1;
         }
     }
     conv_epilogue_rows<EPI, CT, PT>(acc, g, ep, mrow, n0 + wave_n * (16 * CT), lane);
@@ -3009,7 +3022,7 @@ __global__ void k_head_grad_pack(const bf16_raw* __restrict__ dloc, const bf16_r
 struct Knob { const char* name; int value; bool init; };
 Knob g_knobs[] = {{"SSD_ABLATE", 0, false}, {"SSD_DGRAD_S2", 0, false}, {"SSD_CONV_VARIANT", 0, false}, {"SSD_CONV_PATCH", 0, false},
                   {"SSD_CONV_TILE", 0, false}, {"SSD_SPLITK", 0, false}, {"SSD_WGRAD_DMA", 0, false}, {"SSD_WGRAD_PATCH", 0, false},
-                  {"SSD_WGRAD_PATCH_SINGLE", 0, false}, {"SSD_WGRAD_PATCH_SHAPE", 0, false}, {"SSD_WGRAD_TILE", 0, false}, {"SSD_CONV_PATCH_FORM", 0, false}, {"SSD_CONV_PATCH_FLAT", 0, false}, {"SSD_WGRAD_FIRST", 0, false}, {"SSD_CONV_FIRST", 0, false}, {"SSD_WGRAD_PATCH_XCD", 0, false}, {"SSD_CONV_C64", 0, false}, {"SSD_CONV_POOL_FUSE", 0, false}};
+                  {"SSD_WGRAD_PATCH_SINGLE", 0, false}, {"SSD_WGRAD_PATCH_SHAPE", 0, false}, {"SSD_WGRAD_TILE", 0, false}, {"SSD_CONV_PATCH_FORM", 0, false}, {"SSD_CONV_PATCH_FLAT", 0, false}, {"SSD_WGRAD_FIRST", 0, false}, {"SSD_CONV_FIRST", 0, false}, {"SSD_WGRAD_PATCH_XCD", 0, false}, {"SSD_CONV_C64", 0, false}, {"SSD_CONV_POOL_FUSE", 0, false}, {"SSD_CONV_PATCH_ROWFLAT", 0, false}};
 Knob* find_knob(const char* name) {
     for (Knob& k : g_knobs) if (!strcmp(k.name, name)) return &k;
     return nullptr;
@@ -3032,6 +3045,7 @@ ConvGeom make_geom(int B, int H, int W, int C, int Ho, int Wo, int N, int KH, in
     g.cpt = C / 8;
     g.d_hw = make_fastdiv(Ho * Wo);
     g.d_w = make_fastdiv(Wo);
+    g.d_h1 = make_fastdiv(H + 1);
     g.ablate = knob("SSD_ABLATE", 0);
     g.s2 = 0;
     const int s2on = knob("SSD_DGRAD_S2", 1);
@@ -3096,7 +3110,13 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
         if (knob("SSD_CONV_PATCH_FORM", 2) >= 2 && (long long)g.B * g.H * g.W * g.C < (1ll << 31) - 16 &&
             (long long)g.N * g.ldw < (1ll << 31) - 16) {
             const bool flat = use_flat;
-            const unsigned gxx = flat ? (unsigned)(((long long)g.B * (g.H + 1) * (g.W + 2) + 255) / 256) : gx;
+            // wide maps: one strip of rows over all images (k_conv3x3_patch32, "rowflat") when that needs fewer blocks and
+            // the epilogue does not pool (2x2 windows would straddle blocks)
+            const unsigned strip_rows = (unsigned)(((long long)g.B * (g.H + 1) + 15) / 16);
+            const int rowflat = (!flat && !ep.pool_out && knob("SSD_CONV_PATCH_ROWFLAT", 1) &&
+                                 strip_rows < (unsigned)(tiles_y * g.B)) ? 1 : 0;
+            const unsigned gxx = flat ? (unsigned)(((long long)g.B * (g.H + 1) * (g.W + 2) + 255) / 256)
+                                      : (rowflat ? strip_rows * (unsigned)tiles_x : gx);
 #define SSD_LAUNCH_P32(BN_, FLAT_)                                                                                  \
             do {                                                                                                    \
                 constexpr int lds_ = 2 * P32_PATCH + 2 * BN_ * 64 + (BN_ == 64 ? 1024 : 0);                         \
@@ -3108,7 +3128,7 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
                     set_ = true;                                                                                    \
                 }                                                                                                   \
                 const unsigned ntn_ = (unsigned)((g.N + BN_ - 1) / BN_);                                            \
-                hipLaunchKernelGGL(kern_, dim3(8 * ntn_ * ((gxx + 7) / 8)), dim3(512), lds_, s, xp, wp, g, ep, tiles_x, tiles_y, (int)gxx); \
+                hipLaunchKernelGGL(kern_, dim3(8 * ntn_ * ((gxx + 7) / 8)), dim3(512), lds_, s, xp, wp, g, ep, tiles_x, tiles_y, (int)gxx, rowflat); \
             } while (0)
             const bool can_pool = pooled && ep.pool_out && !flat && (g.N & 7) == 0 && (ep.ldo & 7) == 0 && !(g.ablate & 8);
             if (EPI == EPI_FWD && !ep.out && !can_pool) return SSD_ERR_VALUE;

@@ -166,6 +166,32 @@ def test_patch_strip_blocks_forced(ops, case):
         assert (outs[0][1] - outs[1][1]).abs().max().item() <= 2 ** -7 * max(1.0, outs[0][1].abs().max().item())
 
 
+@pytest.mark.parametrize("case", [(3, 21, 21, 64, 128), (2, 45, 50, 128, 96), (5, 19, 40, 64, 72)])
+def test_patch_row_strip_is_bitwise_neutral(ops, case):
+    """Blocks over one strip of rows of all images (SSD_CONV_PATCH_ROWFLAT, default on: a block may straddle two images,
+    which share one zero row) give the same forward and data gradient, bit for bit, as per-image 16x16 blocks."""
+    from ssd_object_detection_amd import _lib
+    B, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((B, H, W, Cin), generator=g).bfloat16().cuda()
+    w = (torch.randn((Cout, 3, 3, Cin), generator=g) / np.sqrt(9 * Cin)).bfloat16().cuda()
+    bias = (torch.randn((Cout,), generator=g) * 0.1).cuda()
+    dy = torch.randn((B, H, W, Cout), generator=g).bfloat16().cuda()
+    L = _lib.lib()
+    outs = []
+    for v in (0, 1):
+        assert L.ssd_dev_knob(b"SSD_CONV_PATCH_ROWFLAT", v) == 0
+        try:
+            y = ops.conv2d_fwd(x, w, bias, 1, 1, 1, H, W, True)
+            dx = ops.conv2d_bwd_data(dy, ops.weight_transpose(w), x, (B, H, W, Cin), 1, 1, 1)
+        finally:
+            L.ssd_dev_knob(b"SSD_CONV_PATCH_ROWFLAT", 1)
+        outs.append((y, dx))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    yr = ref_conv(x.float().cpu(), w.float().cpu(), bias.cpu(), 3, 1, 1, 1, H, W, True)
+    assert (outs[1][0].float().cpu() - yr).abs().max().item() <= 2 ** -7 * max(1.0, yr.abs().max().item())
+
+
 @pytest.mark.parametrize("shape", [0, 1, 2])
 def test_wgrad_patch_block_shapes(ops, shape):
     """Every block shape of the LDS-patch weight-gradient kernel (16x16, 6x40, 10x24) gives the same gradient;

@@ -143,7 +143,7 @@ def main():
         # WRITE_SIZE runs of tools_dev/time_step.py, summed by tools_dev/pmc_conv_traffic.py; FETCH_SIZE doubled: gfx950
         # tallies 128-byte requests at 64 B, MI355X_MICROARCH.md "HBM").  Only valid for the batch it was collected at.
         conv_traffic = None
-        conv_pmc = os.path.join(ROOT, "profiles", "r01_conv_pmc.json")
+        conv_pmc = os.path.join(ROOT, "profiles", "r01d_conv_pmc.json")
         if B == 64 and os.path.exists(conv_pmc):
             conv_traffic = int(json.load(open(conv_pmc))["conv_hbm_bytes_per_step"])
         result["roofline"] = {

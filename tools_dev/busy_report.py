@@ -1,11 +1,12 @@
 """GPU busy fraction from a rocprofv3 kernel trace: busy_report.py <dir>  (union of kernel intervals vs wall, per step)"""
 import csv, glob, sys
-f = glob.glob(sys.argv[1] + '/*/*_kernel_trace.csv')[0]
+f = (glob.glob(sys.argv[1] + '/*/*_kernel_trace.csv') + glob.glob(sys.argv[1] + '/*_kernel_trace.csv'))[0]
 rows = sorted(((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in csv.DictReader(open(f))))
-# steps are delimited by k_adam launches
-adam = [i for i, r in enumerate(rows) if 'k_adam' in r[2]]
-for a, b in zip(adam[-4:-1], adam[-3:]):
-    seg = rows[a + 1:b + 1]
+# a step starts with the first launch of the anchor matching (k_match_rows)
+first = [i for i, r in enumerate(rows) if 'k_match_rows' in r[2]]
+first = [i for j, i in enumerate(first) if j == 0 or i - first[j - 1] > 20]
+for a, b in zip(first[-4:-1], first[-3:]):
+    seg = rows[a:b]
     t0, t1 = seg[0][0], seg[-1][1]
     busy = 0; cur_s, cur_e = seg[0][0], seg[0][1]
     for s, e, _ in seg[1:]:

@@ -3163,10 +3163,15 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
         const long long wg_256 = (long long)((g.M + 255) / 256);
         int bm = 128, bn = g.N <= 64 ? 64 : 128;
         const long long pad256 = (long long)((g.N + 255) / 256) * 256, pad128 = (long long)((g.N + 127) / 128) * 128;
-        if (g.N > 128 && wg_256 * ((g.N + 255) / 256) >= 384 && pad256 * 4 <= pad128 * 5) { bm = 256; bn = 256; }
+        // (>= 352 rather than 384 workgroups: at 364 -- the 19x19 maps with 1024 channels -- the 8-phase kernel's deeper
+        //  pipeline beats the 256x128 kernel's better fill by 12 %.  A third / fourth LDS stage in k_conv_igemm_dma itself was
+        //  tried for the skinny layers and was neutral to 60 % slower: not the DMA latency bounds them)
+        if (g.N > 128 && wg_256 * ((g.N + 255) / 256) >= 352 && pad256 * 4 <= pad128 * 5) { bm = 256; bn = 256; }
         else if (g.N > 64 && wg_256 * ((g.N + 127) / 128) >= 384) { bm = 256; bn = 128; }
         else if (g.N <= 64 && wg_256 >= 384) { bm = 256; bn = 64; }
         if (force == 1) { bm = 128; bn = g.N <= 64 ? 64 : 128; }
+        if (force == 2 && g.N > 128) { bm = 256; bn = 256; }
+        if (force == 3 && g.N > 64) { bm = 256; bn = 128; }
         (void)wg_128;
         // split-K for skinny problems (few tiles, long k loop): partial sums to the caller's workspace
         unsigned ksplit = 1;

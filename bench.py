@@ -49,7 +49,12 @@ def main():
     torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))   # (modulo: lets a 1-GPU box rehearse N ranks)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(os.environ.get("SSD_DIST_BACKEND", "nccl"))
+        backend = os.environ.get("SSD_DIST_BACKEND", "nccl")
+        try:                                    # bind the communicator to this rank's GPU up front (no lazy-init surprises)
+            dist.init_process_group(backend, device_id=torch.device("cuda", torch.cuda.current_device())
+                                    if backend == "nccl" else None)
+        except TypeError:
+            dist.init_process_group(backend)
 
     import ssd_object_detection_amd.ops as ops
     from ssd_object_detection_amd import optimizers
@@ -200,6 +205,7 @@ def main():
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
+        dist.barrier()                          # rank 0 was still timing kernels: leave together
         dist.destroy_process_group()
 
 

@@ -350,11 +350,17 @@ class SSDEngine:
         big = [lvl for lvl, (ni, h, ch) in enumerate(self.fm) if side is not None and B * h * h >= 16384
                and os.environ.get("SSD_BIG_HEADS_SIDE", "1") == "1"]
         head_done = {}                                     # activation index -> event after the head's data gradient
-        packed = []
-        for lvl, (ni, h, ch) in enumerate(self.fm):
-            n = self.num_priors[lvl]
-            packed.append(ops.head_grad_pack(dloc, dconf, h * h, n, self.classes, self.head_npad[lvl],
-                                             self.level_off[lvl], out=c["packed"][lvl]).view(B, h, h, self.head_npad[lvl]))
+        packed = [None] * len(self.fm)
+
+        def pack(lvl):                                     # loc + conf gradients of one level in the head's channel order
+            h = self.fm[lvl][1]
+            packed[lvl] = ops.head_grad_pack(dloc, dconf, h * h, self.num_priors[lvl], self.classes, self.head_npad[lvl],
+                                             self.level_off[lvl], out=c["packed"][lvl]).view(B, h, h, self.head_npad[lvl])
+
+        pack_side = os.environ.get("SSD_PACK_SIDE", "1") == "1"
+        for lvl in range(len(self.fm)):                    # the large levels are packed where they are consumed (side stream)
+            if lvl not in big or not pack_side:
+                pack(lvl)
 
         def head_dgrad(lvl, ws):
             ni = self.fm[lvl][0]
@@ -374,6 +380,8 @@ class SSDEngine:
             with torch.cuda.stream(side):
                 side.wait_event(ev)
                 for lvl in reversed(big):                  # 19x19 first: the trunk chain reaches it first
+                    if pack_side:
+                        pack(lvl)
                     head_dgrad(lvl, self._ws_side)
                     done = torch.cuda.Event()
                     done.record(side)

@@ -250,6 +250,12 @@ class SSDEngine:
         acts[0] = x
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.overlap_heads else None
+        tail = None
+        if side is not None and os.environ.get("SSD_TAIL_STREAM", "1") == "1":
+            if getattr(self, "_tail", None) is None:
+                self._tail = torch.cuda.Stream(device=self.device)
+                self._ws_tail = ops.MatchWorkspace()
+            tail = self._tail
         fm_level = {ni: lvl for lvl, (ni, _, _) in enumerate(self.fm)}
 
         def head(lvl, ws):
@@ -290,11 +296,22 @@ class SSDEngine:
                 with torch.cuda.stream(side):
                     side.wait_event(ev)
                     head(lvl, self._ws_side)
+            elif tail is not None and lvl is not None:
+                # the small levels' heads (10x10 and below: a few workgroups each) on a third stream, as soon as their map
+                # exists: next to the extras' chain on the main stream and the 19x19 head on the side stream they cost
+                # nothing, behind them they were 190 us of a nearly idle GPU
+                ev = torch.cuda.Event()
+                ev.record(main)
+                with torch.cuda.stream(tail):
+                    tail.wait_event(ev)
+                    head(lvl, self._ws_tail)
         for lvl in range(len(self.fm)):
-            if side is None or lvl not in self.SIDE_HEADS:
+            if side is None or (lvl not in self.SIDE_HEADS and tail is None):
                 head(lvl, self._ws)
         if side is not None:
             main.wait_stream(side)
+            if tail is not None:
+                main.wait_stream(tail)
         return c["loc"], c["conf"]
 
     def backward(self, dloc, dconf, on_ready=None, fused_adam=None):

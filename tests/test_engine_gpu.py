@@ -137,3 +137,33 @@ def test_optimizer_vs_oracle(engine):
     bf = engine.param_bf16.float().cpu().numpy()
     assert np.abs(bf - got).max() <= 2 ** -8 * np.abs(got).max()
     engine.init_params(seed=3)
+
+
+def test_full_batch_is_image_independent(engine):
+    """Size-independent property at the benchmark's full size (batch 64): a sample's predictions and the gradient that
+    reaches its activations do not depend on where it sits in the batch or on its neighbours -- blocks of the convolution
+    kernels span image boundaries (row strips, strip blocks, parity classes), split-K and three streams are in play, and
+    none of that may leak between images: permuting the batch permutes predictions and activation gradients bit for bit
+    (same kernels, same tiling), and leaves the weight gradient unchanged up to fp32 summation order."""
+    import ssd_object_detection_amd.ops as ops
+    B = 64
+    g = torch.Generator(device="cuda").manual_seed(77)
+    img = torch.rand((B, 300, 300, 3), generator=g, device="cuda")
+    x = ops.image_prep(img)
+    dloc = (torch.randn((B, 8732, 4), generator=g, device="cuda") * 1e-3).bfloat16()
+    dconf = (torch.randn((B, 8732, 81), generator=g, device="cuda") * 1e-3).bfloat16()
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(5)).cuda()
+
+    def run(xb, dl, dc):
+        loc, conf = engine.forward(xb)
+        loc, conf = loc.clone(), conf.clone()
+        engine.backward(dl, dc)
+        torch.cuda.synchronize()
+        return loc, conf, engine._acts(B)["gacts"][1].clone(), engine.grad.clone()
+
+    loc, conf, g1, grad = run(x, dloc, dconf)
+    loc_p, conf_p, g1_p, grad_p = run(x[perm].contiguous(), dloc[perm].contiguous(), dconf[perm].contiguous())
+    assert torch.equal(loc_p, loc[perm]) and torch.equal(conf_p, conf[perm])
+    assert torch.equal(g1_p, g1[perm])                       # gradient w.r.t. block1_conv1's output, per image
+    err = float((grad_p - grad).norm() / grad.norm())
+    assert err < 1e-3, err                                   # the same products summed in another order

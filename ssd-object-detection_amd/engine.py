@@ -484,19 +484,21 @@ class SSDEngine:
             self._opt_buckets = out
         return self._opt_buckets
 
-    def adam_range(self, t0, t1, lr_t, beta1, beta2, eps, clip):
+    def adam_range(self, t0, t1, lr_t, beta1, beta2, eps, clip, grad_scale=1.0):
         """clip_by_norm + Adam + bf16 / transposed copies for parameter tensors t0..t1-1 on the current stream.
-        Per tensor the arithmetic is that of clip_scales() + adam() over the whole flat buffer, bit for bit."""
+        Per tensor the arithmetic is that of clip_scales() + adam() over the whole flat buffer, bit for bit.
+        clip=None: the gradient is already clipped (and summed over ranks): only grad_scale (1 / world) applies."""
         b0, tbo, bt = self._range_table(t0, t1)
         start, n = b0 * self.block, bt.numel() * self.block
         sl = slice(start, start + n)
-        _lib.check(self.L.ssd_grad_clip_scales(ops._ptr(self.grad[sl]), n, ops._ptr(tbo), t1 - t0, float(clip),
-                                               ops._ptr(self.sq_partial[b0:]), ops._ptr(self.clip_scale[t0:]),
-                                               ops._ptr(self.grad_norms[t0:]), ops._stream()))
+        if clip is not None:
+            _lib.check(self.L.ssd_grad_clip_scales(ops._ptr(self.grad[sl]), n, ops._ptr(tbo), t1 - t0, float(clip),
+                                                   ops._ptr(self.sq_partial[b0:]), ops._ptr(self.clip_scale[t0:]),
+                                                   ops._ptr(self.grad_norms[t0:]), ops._stream()))
         _lib.check(self.L.ssd_adam_step(ops._ptr(self.param[sl]), ops._ptr(self.grad[sl]), ops._ptr(self.adam_m[sl]),
                                         ops._ptr(self.adam_v[sl]), ops._ptr(self.param_bf16[sl]), n, ops._ptr(bt),
-                                        ops._ptr(self.clip_scale[t0:]), 1.0, float(lr_t), float(beta1), float(beta2),
-                                        float(eps), ops._stream()))
+                                        ops._ptr(self.clip_scale[t0:]) if clip is not None else None, float(grad_scale),
+                                        float(lr_t), float(beta1), float(beta2), float(eps), ops._stream()))
         self.refresh_weights(tensors=(t0, t1))
 
     def clip_range_in_place(self, t0, t1, clip=0.01):

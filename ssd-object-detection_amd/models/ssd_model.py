@@ -12,6 +12,7 @@ What differs from the reference, by design:
   * inference adds a real NMS pass (`detect`), which the reference lacks.
 """
 import logging
+import math
 import os
 import time
 
@@ -178,6 +179,9 @@ class SSDObjectDetectionModel:
             self._reducer = GradReducer(eng.grad, [t.offset for t in eng.tensors], blocks, eng.block,
                                         eng.clip_range_in_place)
         fused = single and isinstance(ssd_optimizer, _opt.Adam) and self.fused_optimizer
+        fused_dp = overlap and isinstance(ssd_optimizer, _opt.Adam) and self.fused_optimizer
+        if fused_dp:
+            self._adopt_slots(ssd_optimizer)
         if fused:                                      # the optimizer runs per bucket inside the backward pass
             self._adopt_slots(ssd_optimizer)
             eng.step_count = ssd_optimizer.iterations
@@ -198,7 +202,15 @@ class SSDObjectDetectionModel:
             if overlap:
                 self._reducer.begin()
                 eng.backward(info["dloc"], info["dconf"], on_ready=self._reducer.tensor_ready)
-                self._reducer.finish()                 # clipped per bucket, summed over ranks (RCCL over xGMI)
+                post = None
+                if fused_dp:                           # Adam of a bucket right behind its all-reduce, on the comm stream
+                    eng.step_count = ssd_optimizer.iterations + 1
+                    t = eng.step_count
+                    lr = ssd_optimizer.lr()
+                    b1, b2 = ssd_optimizer.beta_1, ssd_optimizer.beta_2
+                    lr_t = lr * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+                    post = lambda t0, t1: eng.adam_range(t0, t1, lr_t, b1, b2, ssd_optimizer.epsilon, None, 1.0 / world)
+                self._reducer.finish(post)             # clipped per bucket, summed over ranks (RCCL over xGMI)
             elif fused:
                 eng.backward(info["dloc"], info["dconf"], fused_adam=fused_adam)
             else:
@@ -207,7 +219,7 @@ class SSDObjectDetectionModel:
                 if not single:
                     eng.accumulate_clipped(first=(n_micro == 0))
             n_micro += 1
-        if fused:
+        if fused or fused_dp:
             ssd_optimizer.iterations += 1
             return self._finish_step(info, lr, pred_conf, pred_loc)
         self._adopt_slots(ssd_optimizer)

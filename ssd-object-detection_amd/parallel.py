@@ -85,10 +85,26 @@ class GradReducer:
             self.clip_fn(t0, t1)
             self.handles.append(dist.all_reduce(view, group=self.group, async_op=True))
 
-    def finish(self):
+    def finish(self, post_fn=None):
+        """Wait for the exchange.  post_fn(t0, t1), if given, is run for every bucket right behind its all-reduce (on the
+        communication stream, once everything the caller has enqueued so far is done): the optimizer step of a bucket
+        then overlaps the all-reduce of the next ones instead of waiting for the last."""
         assert self.next_bucket == len(self.buckets), "backward did not report every tensor"
-        for h in self.handles:
+        if post_fn is not None and self.use_streams:
+            ev = torch.cuda.Event()
+            ev.record()                                   # the caller's stream: the whole backward pass is enqueued
+            with torch.cuda.stream(self.comm):
+                self.comm.wait_event(ev)
+                for h, (t0, t1) in zip(self.handles, self.buckets):
+                    h.wait()
+                    post_fn(t0, t1)
+            torch.cuda.current_stream().wait_stream(self.comm)
+            self.handles = []
+            return
+        for h, (t0, t1) in zip(self.handles, self.buckets):
             h.wait()
+            if post_fn is not None:
+                post_fn(t0, t1)
         if self.use_streams:
             torch.cuda.current_stream().wait_stream(self.comm)
         self.handles = []

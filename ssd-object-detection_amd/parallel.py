@@ -10,7 +10,8 @@ The flat gradient buffer is laid out in forward order and the backward pass comp
 then conv22 ... conv0), so buckets are contiguous ranges taken from the end of the buffer.  As soon as the last
 tensor of a bucket has its weight gradient enqueued, the bucket is clipped in place and all-reduced on a side
 stream while the compute stream keeps running the (FLOP-heavy, parameter-light) VGG layers.  xGMI is point to
-point (7 links x ~153 GB/s per GPU): few, large messages; the default 4 buckets of ~25 MB each.
+point (7 links x ~153 GB/s per GPU): few, large messages; the default 6 buckets: ~17-20 MB each for SSD300, and what is
+left for the last one -- the only exchange that cannot overlap the backward pass -- is block1..block3 (4.6 MB).
 """
 import torch
 import torch.distributed as dist
@@ -38,7 +39,7 @@ class GradReducer:
     clip_fn(t0, t1) must clip tensors t0..t1-1 of the flat buffer in place (on the current stream / synchronously on
     CPU); it is how the engine's HIP kernels are plugged in, and how CPU tests plug in a numpy reference."""
 
-    def __init__(self, flat_grad, tensor_offsets, tensor_blocks, block_elems, clip_fn, n_buckets=4, group=None):
+    def __init__(self, flat_grad, tensor_offsets, tensor_blocks, block_elems, clip_fn, n_buckets=6, group=None):
         self.flat = flat_grad
         self.offsets = list(tensor_offsets)
         self.blocks = list(tensor_blocks)

@@ -270,7 +270,7 @@ def cpu_baseline(np, torch):
     one_step()                                  # warm
     reps, tot, tmatch = 0, 0.0, 0.0
     t_begin = time.perf_counter()
-    while time.perf_counter() - t_begin < 12.0 and reps < 6:
+    while time.perf_counter() - t_begin < 12.0 and reps < 40:
         t = one_step()
         tot += t["match"] + t["net+loss"]
         tmatch += t["match"]

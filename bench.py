@@ -1,18 +1,24 @@
 #!/usr/bin/env python3
-"""Benchmark of the SSD300 data-parallel hot path on MI355X (contract: see the task prompt / DESIGN.md).
+"""Benchmark of the SSD300 data-parallel hot path on MI355X (contract: see the task prompt / DESIGN.md section 8).
 
 One "step" = one full training step of the reference's path on one batch of synthetic input that is already
-resident in HBM: batched anchor matching + encoding (A3-A5), image normalisation to bf16, conv stack forward
-(A1), loss forward+backward (A6), conv stack backward, per-tensor clip + Adam (A7); with N > 1 ranks, one RCCL
-all-reduce of the clipped gradients.  Workload = BASELINE.json configs[2]: SSD300, per-GPU batch 64.
+resident in HBM: batched anchor matching + encoding (A3-A5), image normalisation (x-0.5)*2 to bf16 (A8), conv stack
+forward (A1), loss forward+backward (A6), conv stack backward, per-variable clip + Adam (A7); with N > 1 ranks, one
+bucketed RCCL all-reduce of the clipped gradients.  Workload = BASELINE.json configs[2]: SSD300, per-GPU batch 64.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernels (the conv implicit GEMMs, MFMA-bound);
-`roofline_match` is the HBM-bound anchor-matching kernel; `cpu_baseline` is the oracle port of the same step
-timed on this host's cores.
+`python bench.py --gpus N` starts the N rank processes itself (children are spawned before the parent touches a GPU;
+nothing is exec'ed); under torch.distributed.run (WORLD_SIZE set) it is one of the ranks.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the convolution launches (MFMA-bound); `roofline_match`,
+`roofline_loss`, `roofline_detect` (score + decode + NMS) and `roofline_prep` are the HBM-bound stages; `m2` is the
+BASELINE metric's second half (anchor-match + NMS microseconds per image); `cfg5_anchors` runs the anchor-side kernels at
+BASELINE configs[4]'s 24 564 anchors; `cpu_baseline` is the oracle port timed on this host's cores.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,10 +29,13 @@ FLOP_FWD_PER_IMAGE = 57.554e9
 FLOP_TRAIN_PER_IMAGE = 172.66e9 - 0.31e9   # fwd + dgrad + wgrad, first-layer dgrad not needed
 PEAK_BF16_TFLOPS = 2500.0               # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
-MATCH_BYTES_PER_IMAGE = 8732 * 53       # + 20 * n_t  
+MATCH_BYTES_PER_ANCHOR = 53             # priors f64 in (32) + cls i32 + loc f32x4 + mask u8 out; + 20 B per gt box
+CFG5_GRIDS = ((64, 64), (32, 32), (16, 16), (8, 8), (4, 4), (2, 2), (1, 1))      # A = 24 564
+CFG5_RATIOS = ((2,), (2, 3), (2, 3), (2, 3), (2, 3), (2,), (2,))
+CFG5_S_REF = (20, 51, 133, 215, 297, 379, 461, 543)      # SSD512-style scales / 512 (no reference counterpart)
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -34,8 +43,97 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE config: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+# --------------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: the parent only spawns and waits
+# --------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    import torch                                     # device_count() does not initialise the GPU
+    n_dev = torch.cuda.device_count()
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in env:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            env["MASTER_PORT"] = str(s.getsockname()[1])
+    if n_dev < args.gpus:                            # rehearsal on a smaller box: ranks share GPUs, RCCL cannot
+        env.setdefault("SSD_DIST_BACKEND", "gloo")
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(args.gpus):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()                                 # exactly the PID we started
+            p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return rc
+
+
+# --------------------------------------------------------------------------------------------------------------------
+def timed(torch, fn, reps, warm=1):
+    """Average seconds per call from HIP events on the current stream (the stream the C ABI launches on)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+def graph_timed(torch, fn, reps):
+    """The same with the call captured in a hipGraph (host launch overhead is not in the number)."""
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        fn()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            fn()
+    return timed(torch, g.replay, reps)
+
+
+def hbm_entry(kernel, nbytes, seconds, per_image, **extra):
+    d = {"bound": "hbm", "kernel": kernel, "achieved": round(nbytes / seconds / 1e9, 1), "peak": PEAK_HBM_GBS,
+         "unit": "GB/s", "frac": round(nbytes / seconds / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+         "algorithmic_bytes": int(nbytes), "us_per_image": round(seconds / per_image * 1e6, 4)}
+    d.update(extra)
+    return d
+
+
+def pmc_profile(name):
+    """Newest committed PMC summary profiles/r*_<name>.json (collected by separate rocprofv3 --pmc passes, see
+    tools_dev/collect_pmc.sh) or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s.json" % name)))
+    return (json.load(open(files[-1])), os.path.basename(files[-1])) if files else (None, None)
+
+
+def nms_inputs(torch, B, A, dtype, seed=7):
+    """SURVEY.md 8(d) NMS input: logits N(0,1) with the background logit +4, box offsets N(0, 0.5)."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    conf = torch.randn((B, A, 81), generator=g, device="cuda")
+    conf[..., 80] += 4.0
+    loc = torch.randn((B, A, 4), generator=g, device="cuda") * 0.5
+    return conf.to(dtype).contiguous(), loc.to(dtype).contiguous()
+
+
+def run_rank(args):
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -43,10 +141,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        print("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
-        sys.exit(2)
     torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))   # (modulo: lets a 1-GPU box rehearse N ranks)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("SSD_DIST_BACKEND", "nccl")
@@ -67,14 +163,14 @@ def main():
     eng = model.get_engine()
     opt = optimizers.Adam(optimizers.ExponentialDecay(1e-3, 100, 0.99), beta_1=0.9, beta_2=0.999, epsilon=1e-7)
 
-    # synthetic input, resident in HBM: NBATCH distinct batches cycled (images uniform[0,1), COCO-shaped boxes)
+    # synthetic input, resident in HBM: NBATCH distinct batches cycled (images uniform[0,1) f32 as the loader contract
+    # delivers them, COCO-shaped boxes); the normalisation (x-0.5)*2 of get_train_set (reference :214) runs inside the step
     NBATCH = 2
     gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
     batches = []
     for i in range(NBATCH):
         img = torch.rand((B, 300, 300, 3), generator=gen, device="cuda", dtype=torch.float32)
         cls_l, box_l = synth_batch_gt((rank * NBATCH + i) * B, B)
-        img = (img - 0.5) * 2            # get_train_set delivers normalised images (reference :214); done once, untimed
         batches.append((img, ops.pack_gt(box_l, cls_l)))
     pset = model._pset
     match_out = None
@@ -84,7 +180,8 @@ def main():
         img, gt = batches[i % NBATCH]
         match_out = model.match_async(gt, out=match_out)     # A3-A5 on the device, side stream, under the forward pass
         cls, loc, mask = match_out
-        model._train_step(img, cls, loc, mask, opt)
+        x = ops.image_prep(img, normalize=True)              # A8: (x-0.5)*2, bf16, 8 channels -- one fused pass
+        model._train_step(x, cls, loc, mask, opt)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -92,18 +189,24 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed_steps(n, first=0):
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(n):
+            step(first + i)
+        sync_all()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     for i in range(args.warmup):
         step(i)
-    sync_all()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if world > 1 and model._reducer is not None:
+        model._reducer.profile = True           # two events per bucket on the communication stream
+    elapsed = timed_steps(args.steps)
     status = float(model.last_info["status"])
     loss_vals = {k: float(model.last_info[k]) for k in ("loc loss", "cls loss pos", "cls loss neg")}
 
@@ -114,90 +217,21 @@ def main():
         "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[2]: SSD300 full train step (anchor match+encode, conv fwd, loss, conv bwd, "
-                               "per-tensor clip + Adam), per-GPU batch %d, 80 classes, synthetic COCO-shaped boxes" % B,
+        "config": {"workload": "BASELINE configs[2]: SSD300 full train step (anchor match+encode, image normalisation, conv fwd, "
+                               "loss, conv bwd, per-variable clip (64 variables) + Adam), per-GPU batch %d, 80 classes, "
+                               "synthetic COCO-shaped boxes" % B,
                    "per_gpu_batch": B, "global_batch": B * world,
                    "parallelism": "dp%d" % world if world > 1 else "single"},
         "loss_check": dict(loss_vals, status=status),
         "frac_of_conv_gemm_roofline": round(FLOP_TRAIN_PER_IMAGE * value / (world * PEAK_BF16_TFLOPS * 1e12), 4),
     }
 
+    if world > 1:
+        result["comm"] = comm_report(torch, dist, model, backend, world, elapsed / args.steps, timed_steps,
+                                     min(args.steps, 10), args.warmup + args.steps)
+
     if rank == 0 and not args.no_kernel_timing:
-        # ---- per-kernel timing with HIP events on the launch stream (outside the timed region) ----
-        def timed(fn, reps):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            fn()
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(reps):
-                fn()
-            e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / reps * 1e-3
-
-        img, gt = batches[0]
-        x = ops.image_prep(img, normalize=False)
-        cls, loc, mask = match_out
-        t_fwd = timed(lambda: eng.forward(x), 3)
-        ploc, pconf = eng.forward(x)
-        _, dconf, dloc = ops.ssd_loss(pconf, ploc, cls, loc, mask)
-        t_bwd = timed(lambda: eng.backward(dloc, dconf), 3)
-        conv_flops = FLOP_TRAIN_PER_IMAGE * B
-        conv_time = t_fwd + t_bwd
-        # memory-side traffic of the convolution launches of one step, from rocprofv3 PMC passes (separate --pmc FETCH_SIZE /
-        # WRITE_SIZE runs of tools_dev/time_step.py, summed by tools_dev/pmc_conv_traffic.py; FETCH_SIZE doubled: gfx950
-        # tallies 128-byte requests at 64 B, MI355X_MICROARCH.md "HBM").  Only valid for the batch it was collected at.
-        conv_traffic = None
-        conv_pmc = os.path.join(ROOT, "profiles", "r01d_conv_pmc.json")
-        if B == 64 and os.path.exists(conv_pmc):
-            conv_traffic = int(json.load(open(conv_pmc))["conv_hbm_bytes_per_step"])
-        result["roofline"] = {
-            "bound": "mfma", "kernel": "all convolution launches of one step (k_conv3x3_patch32, k_conv3x3_wgrad_patch, k_conv_igemm_*, k_conv_wgrad_*, k_conv0_*)",
-            "achieved": round(conv_flops / conv_time / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(conv_flops / conv_time / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": conv_traffic,
-            "fwd_ms": round(t_fwd * 1e3, 3), "bwd_ms": round(t_bwd * 1e3, 3),
-            "fwd_tflops": round(FLOP_FWD_PER_IMAGE * B / t_fwd / 1e12, 2)}
-        # anchor matching: graph-replayed so that host launch overhead is not in the number
-        total_gt = gt[3]
-        g = torch.cuda.CUDAGraph()
-        s = torch.cuda.Stream()
-        with torch.cuda.stream(s):
-            ops.match_encode(*gt, pset, 0.5, out=match_out)
-            torch.cuda.synchronize()
-            with torch.cuda.graph(g, stream=s):
-                ops.match_encode(*gt, pset, 0.5, out=match_out)
-        t_match = timed(lambda: g.replay(), 50)
-        mbytes = B * MATCH_BYTES_PER_IMAGE + 20 * total_gt
-        # HBM traffic of the dominant matching kernel from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE
-        # runs of tools_dev/time_match.py 64:mix; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
-        traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_match_pmc.json")
-        if B == 64 and os.path.exists(pmc_file):
-            pmc = json.load(open(pmc_file))
-            traffic = int((2 * pmc["k_match_pairs.FETCH_SIZE"] + pmc["k_match_pairs.WRITE_SIZE"]) * 1024)
-        result["roofline_match"] = {
-            "bound": "hbm", "kernel": "ssd_match_encode (k_match_rows + k_match_pairs + k_match_phase1)",
-            "achieved": round(mbytes / t_match / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": round(mbytes / t_match / 1e9 / PEAK_HBM_GBS, 4), "traffic": traffic,
-            "algorithmic_bytes": mbytes, "us_per_image": round(t_match / B * 1e6, 4), "total_gt": total_gt}
-
-        # N1: device-side input preprocessing of a batch of COCO-sized uint8 images, HBM-bound:
-        # algorithmic bytes = the source bytes read once + the bf16 [B,300,300,8] network input written once
-        from ssd_object_detection_amd.data_loaders.synthetic import synth_raw_sample
-        raw = [synth_raw_sample(i)[0] for i in range(B)]
-        hw = np.array([r.shape[:2] for r in raw], np.int32)
-        sizes = [int(r.size) for r in raw]
-        off = np.zeros(B, np.int64)
-        off[1:] = np.cumsum(sizes[:-1])
-        flat = torch.from_numpy(np.concatenate([r.reshape(-1) for r in raw])).cuda()
-        off_d, hw_d = torch.from_numpy(off).cuda(), torch.from_numpy(hw).cuda()
-        xprep = ops.image_resize_prep(flat, off_d, hw_d, 300, True)
-        t_prep = timed(lambda: ops.image_resize_prep(flat, off_d, hw_d, 300, True, out=xprep), 20)
-        pbytes = int(sum(sizes)) + B * 300 * 300 * 8 * 2
-        result["roofline_prep"] = {
-            "bound": "hbm", "kernel": "ssd_image_resize_prep (k_image_resize_prep)", "achieved": round(pbytes / t_prep / 1e9, 1),
-            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(pbytes / t_prep / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
-            "algorithmic_bytes": pbytes, "us_per_image": round(t_prep / B * 1e6, 3)}
+        kernel_sections(np, torch, ops, model, eng, pset, batches, match_out, B, result)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(np, torch)
@@ -208,6 +242,154 @@ def main():
         dist.barrier()                          # rank 0 was still timing kernels: leave together
         dist.destroy_process_group()
 
+
+def comm_report(torch, dist, model, backend, world, step_s, timed_steps, n_local, first):
+    """What the gradient exchange costs: rank count as the communicator reports it, every bucket's all-reduce timed alone
+    (bytes, ms, bus bandwidth 2(N-1)/N * bytes / t), its in-step time from events on the communication stream, and the
+    exposed (non-overlapped) part = DP step time - the same step with the exchange switched off (MAX over ranks both)."""
+    red = model._reducer
+    out = {"backend": backend + (" (RCCL over xGMI)" if backend == "nccl" else " (rehearsal: ranks share a GPU)"),
+           "ranks_in_communicator": dist.get_world_size(), "buckets": []}
+    in_step = red.bucket_times_ms() if red is not None else []
+    if red is not None:
+        for k, (t0, t1) in enumerate(red.buckets):
+            start, end = red._range(t0, t1)
+            view = red.flat[start:end]
+            scratch = view.clone()
+            torch.cuda.synchronize()
+            dist.barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            dist.all_reduce(scratch)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(5):
+                dist.all_reduce(scratch)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            nbytes = (end - start) * 4
+            out["buckets"].append({"tensors": [t0, t1], "bytes": nbytes, "allreduce_alone_ms": round(ms, 3),
+                                   "busbw_GBs": round(2 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9, 1),
+                                   "in_step_ms": round(in_step[k], 3) if k < len(in_step) else None})
+    # the same step without the exchange (every rank on its own): what remains is the exposed communication
+    model.distributed = False
+    dt_local = timed_steps(n_local, first) / n_local
+    model.distributed = True
+    out["step_ms"] = round(step_s * 1e3, 3)
+    out["step_without_exchange_ms"] = round(dt_local * 1e3, 3)
+    out["exposed_comm_ms"] = round(max(0.0, step_s - dt_local) * 1e3, 3)
+    return out
+
+
+def kernel_sections(np, torch, ops, model, eng, pset, batches, match_out, B, result):
+    """Per-stage timing with HIP events on the launch stream (outside the timed region)."""
+    img, gt = batches[0]
+    x = ops.image_prep(img, normalize=True)
+    cls, loc, mask = match_out
+    t_fwd = timed(torch, lambda: eng.forward(x), 3)
+    ploc, pconf = eng.forward(x)
+    _, dconf, dloc = ops.ssd_loss(pconf, ploc, cls, loc, mask)
+    t_bwd = timed(torch, lambda: eng.backward(dloc, dconf), 3)
+    conv_flops = FLOP_TRAIN_PER_IMAGE * B
+    conv_time = t_fwd + t_bwd
+    # memory-side traffic of the convolution launches of one step, from rocprofv3 PMC passes (separate --pmc FETCH_SIZE /
+    # WRITE_SIZE runs, FETCH_SIZE doubled: gfx950 tallies 128-byte requests at 64 B, MI355X_MICROARCH.md "HBM"); the file
+    # records the commit it was collected at.  Only valid for the batch it was collected at.
+    conv_pmc, conv_pmc_file = pmc_profile("conv_pmc")
+    conv_traffic = int(conv_pmc["conv_hbm_bytes_per_step"]) if (B == 64 and conv_pmc) else None
+    result["roofline"] = {
+        "bound": "mfma", "kernel": "all convolution launches of one step (k_conv3x3_patch32, k_conv3x3_wgrad_patch, k_conv_igemm_*, k_conv_wgrad_*, k_conv0_*)",
+        "achieved": round(conv_flops / conv_time / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(conv_flops / conv_time / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": conv_traffic,
+        "traffic_source": conv_pmc_file, "traffic_commit": (conv_pmc or {}).get("commit"),
+        "fwd_ms": round(t_fwd * 1e3, 3), "bwd_ms": round(t_bwd * 1e3, 3),
+        "fwd_tflops": round(FLOP_FWD_PER_IMAGE * B / t_fwd / 1e12, 2)}
+
+    # ---- anchor matching (A3-A5): graph-replayed ----
+    total_gt = gt[3]
+    t_match = graph_timed(torch, lambda: ops.match_encode(*gt, pset, 0.5, out=match_out), 50)
+    mbytes = B * pset.A * MATCH_BYTES_PER_ANCHOR + 20 * total_gt
+    mpmc, mpmc_file = pmc_profile("match_pmc")
+    mtraffic = None
+    if B == 64 and mpmc:
+        mtraffic = int(sum(2 * v if k.endswith("FETCH_SIZE") else v for k, v in mpmc.items()
+                           if k.endswith(("FETCH_SIZE", "WRITE_SIZE"))) * 1024)
+    result["roofline_match"] = hbm_entry("ssd_match_encode", mbytes, t_match, B, traffic=mtraffic, traffic_source=mpmc_file,
+                                         traffic_commit=(mpmc or {}).get("commit"), total_gt=total_gt,
+                                         floor_us_at_6300GBs=round(mbytes / 6.3e12 * 1e6, 2), batch_us=round(t_match * 1e6, 2))
+
+    # ---- loss forward + backward (A6) on the network's bf16 logits of this batch ----
+    t_loss = graph_timed(torch, lambda: ops.ssd_loss(pconf, ploc, cls, loc, mask), 30)
+    s = pconf.element_size()
+    lbytes = B * pset.A * (2 * 81 * s + 2 * 4 * s + 16 + 4 + 1)      # conf+loc in, dconf+dloc out, gloc f32x4, cls i32, mask u8
+    result["roofline_loss"] = hbm_entry("ssd_loss_fwd_bwd (k_loss_rows, k_loss_hist/select, k_loss_grad, k_loss_final)",
+                                        lbytes, t_loss, B, logits="bf16", batch_us=round(t_loss * 1e6, 2))
+
+    # ---- inference post-processing (A9 + A9'): score + decode + per-class NMS on the SURVEY 8(d) NMS input ----
+    result["roofline_detect"], m2_detect = detect_section(torch, ops, pset, B, torch.float32)
+    result["roofline_detect"]["bf16_logits"] = detect_section(torch, ops, pset, B, torch.bfloat16)[1]
+    result["m2"] = {"metric": "anchor-match + NMS microseconds per image, batch %d" % B,
+                    "match_encode_us": round(t_match / B * 1e6, 4), "score_decode_us": m2_detect["score_decode_us"],
+                    "nms_us": m2_detect["nms_us"],
+                    "total_us": round(t_match / B * 1e6 + m2_detect["score_decode_us"] + m2_detect["nms_us"], 4)}
+
+    # ---- N1 (SURVEY.md 8f): device-side input preprocessing of a batch of COCO-sized uint8 images ----
+    from ssd_object_detection_amd.data_loaders.synthetic import synth_raw_sample
+    raw = [synth_raw_sample(i)[0] for i in range(B)]
+    hw = np.array([r.shape[:2] for r in raw], np.int32)
+    sizes = [int(r.size) for r in raw]
+    off = np.zeros(B, np.int64)
+    off[1:] = np.cumsum(sizes[:-1])
+    flat = torch.from_numpy(np.concatenate([r.reshape(-1) for r in raw])).cuda()
+    off_d, hw_d = torch.from_numpy(off).cuda(), torch.from_numpy(hw).cuda()
+    xprep = ops.image_resize_prep(flat, off_d, hw_d, 300, True)
+    t_prep = timed(torch, lambda: ops.image_resize_prep(flat, off_d, hw_d, 300, True, out=xprep), 20)
+    pbytes = int(sum(sizes)) + B * 300 * 300 * 8 * 2
+    result["roofline_prep"] = hbm_entry("ssd_image_resize_prep (k_image_resize_prep)", pbytes, t_prep, B)
+
+    # ---- BASELINE configs[4] anchor side: 24 564 anchors through priors -> match -> loss -> score/decode -> NMS ----
+    result["cfg5_anchors"] = cfg5_section(torch, ops, B)
+
+
+def detect_section(torch, ops, pset, B, dtype, score_thresh=0.3, iou_thresh=0.45):
+    conf, loc = nms_inputs(torch, B, pset.A, dtype)
+    sd = ops.score_decode(conf, loc, pset, score_thresh)
+    score, dcls, box, cand = sd
+    ncand = float(cand.sum().item()) / B
+    t_sd = graph_timed(torch, lambda: ops.score_decode(conf, loc, pset, score_thresh), 30)
+    t_nms = graph_timed(torch, lambda: ops.nms(score, dcls, box, cand, iou_thresh, 400), 30)
+    keep = ops.nms(score, dcls, box, cand, iou_thresh, 400)
+    nbytes = B * pset.A * (81 + 4) * conf.element_size()
+    per = {"score_decode_us": round(t_sd / B * 1e6, 4), "nms_us": round(t_nms / B * 1e6, 4),
+           "candidates_per_image": round(ncand, 1), "kept_per_image": round(float(keep.sum().item()) / B, 1)}
+    entry = hbm_entry("ssd_score_decode + ssd_nms (k_score_decode, k_nms)", nbytes, t_sd + t_nms, B,
+                      logits=str(dtype).replace("torch.", ""), **per)
+    entry["score_decode_GBs"] = round((nbytes + B * pset.A * 25) / t_sd / 1e9, 1)     # + score, cls, box, cand written
+    per["GBs"] = entry["achieved"]
+    return entry, per
+
+
+def cfg5_section(torch, ops, B):
+    from ssd_object_detection_amd.data_loaders.synthetic import synth_batch_gt
+    ps = ops.build_priors(grids=CFG5_GRIDS, s_ref=CFG5_S_REF, ratios=CFG5_RATIOS, in_size=512)
+    A = ps.A
+    cls_l, box_l = synth_batch_gt(5000, B)
+    gt = ops.pack_gt(box_l, cls_l)
+    out = ops.match_encode(*gt, ps, 0.5)
+    t_match = graph_timed(torch, lambda: ops.match_encode(*gt, ps, 0.5, out=out), 30)
+    conf, loc = nms_inputs(torch, B, A, torch.bfloat16, seed=11)
+    t_loss = graph_timed(torch, lambda: ops.ssd_loss(conf, loc, *out), 20)
+    score, dcls, box, cand = ops.score_decode(conf, loc, ps, 0.3, 512.0)
+    t_sd = graph_timed(torch, lambda: ops.score_decode(conf, loc, ps, 0.3, 512.0), 20)
+    t_nms = graph_timed(torch, lambda: ops.nms(score, dcls, box, cand, 0.45, 400), 20)
+    mbytes = B * A * MATCH_BYTES_PER_ANCHOR + 20 * gt[3]
+    lbytes = B * A * (2 * 81 * 2 + 2 * 4 * 2 + 21)
+    return {"config": {"workload": "BASELINE configs[4] anchors: A=%d (grids 64,32,16,8,4,2,1; per cell 4,6,6,6,6,4,4), batch %d, "
+                                   "anchor-side kernels only (no ResNet-50 / fp8 convolutions); no reference counterpart" % (A, B)},
+            "match_encode_us_per_image": round(t_match / B * 1e6, 4), "match_GBs": round(mbytes / t_match / 1e9, 1),
+            "loss_us_per_image": round(t_loss / B * 1e6, 4), "loss_GBs": round(lbytes / t_loss / 1e9, 1),
+            "score_decode_us_per_image": round(t_sd / B * 1e6, 4), "nms_us_per_image": round(t_nms / B * 1e6, 4),
+            "candidates_per_image": round(float(cand.sum().item()) / B, 1)}
 
 
 def _usable_cores():
@@ -223,10 +405,12 @@ def _usable_cores():
         pass
     return max(1, n)
 
+
 def cpu_baseline(np, torch):
-    """The oracle port of the same step on the host cores, on a bounded sample: anchor matching by the literal C
-    restatement of utils/bbox.py (one thread, as the reference's generator is), network forward/backward by the
-    plain-PyTorch fp32 restatement on all cores, loss by the numpy float64 restatement."""
+    """The oracle port of the same step on the host cores, on a bounded sample (about 25 s): anchor matching by the literal
+    C restatement of utils/bbox.py (one thread, as the reference's generator is; plus a per-n_t sweep and an all-cores
+    run, one image per worker), network forward/backward by the plain-PyTorch fp32 restatement on all cores, loss by the
+    numpy float64 restatement, NMS by the C restatement of the build-defined NMS."""
     from oracle import c_oracle, net_oracle, ssd_oracle as O
     from ssd_object_detection_amd.engine import SSD300_TRUNK, SSD300_NUM_PRIORS
     from ssd_object_detection_amd.data_loaders.synthetic import synth_batch_gt
@@ -275,10 +459,57 @@ def cpu_baseline(np, torch):
         tot += t["match"] + t["net+loss"]
         tmatch += t["match"]
         reps += 1
-    return {"value": round(Bc * reps / tot, 3), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "%d steps of batch %d (same step: C port of utils/bbox.py matching single-threaded, torch-CPU fp32 "
-                      "network fwd+bwd on all cores, numpy f64 loss); TensorFlow itself is not installable here" % (reps, Bc),
-            "match_us_per_image_1core": round(tmatch / (Bc * reps) * 1e6, 1)}
+    out = {"value": round(Bc * reps / tot, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+           "sample": "%d steps of batch %d (same step: C port of utils/bbox.py matching single-threaded, torch-CPU fp32 "
+                     "network fwd+bwd on all cores, numpy f64 loss); TensorFlow itself is not installable here" % (reps, Bc),
+           "match_us_per_image_1core": round(tmatch / (Bc * reps) * 1e6, 1)}
+
+    # matching by ground-truth count (SURVEY.md 8(d) sweep), one core, bounded to ~1 s per point
+    sweep = {}
+    for n_t in (1, 8, 32, 64, 93):
+        cl, bl = synth_batch_gt(7000, 3, n_t=n_t)
+        t0, n = time.perf_counter(), 0
+        while n < 3 and time.perf_counter() - t0 < 1.5:
+            c_oracle.match_encode(cl[n], bl[n], pri, 0.5)
+            n += 1
+        sweep[str(n_t)] = round((time.perf_counter() - t0) / n * 1e6, 1)
+    out["match_us_per_image_1core_by_nt"] = sweep
+    # one worker thread per core over the images of a COCO-shaped batch (ctypes releases the GIL inside the C matcher, so
+    # threads are real parallelism here and no process is forked from one that holds the GPU)
+    from concurrent.futures import ThreadPoolExecutor
+    cl, bl = synth_batch_gt(0, 64)
+    with ThreadPoolExecutor(cores) as pool:
+        t0 = time.perf_counter()
+        list(pool.map(lambda cb: c_oracle.match_encode(cb[0], cb[1], pri, 0.5)[0][0], zip(cl, bl)))
+        out["match_us_per_image_all_cores"] = round((time.perf_counter() - t0) / 64 * 1e6, 1)
+    # NMS (build-defined; C restatement) on the same kind of input as roofline_detect, one core
+    r2 = np.random.default_rng(7)
+    conf = r2.standard_normal((4, 8732, 81)).astype(np.float32)
+    conf[..., 80] += 4.0
+    loc = (r2.standard_normal((4, 8732, 4)) * 0.5).astype(np.float32)
+    t_sd = t_nms = 0.0
+    ncand = 0
+    for i in range(4):
+        t0 = time.perf_counter()
+        sc, cl_, cand = O.score(conf[i], 0.3)
+        box = O.decode(loc[i], pri).astype(np.float32)
+        t1 = time.perf_counter()
+        c_oracle.nms(sc.astype(np.float32), cl_.astype(np.int32), box, cand, 0.45, 400)
+        t2 = time.perf_counter()
+        t_sd += t1 - t0
+        t_nms += t2 - t1
+        ncand += int(np.sum(cand))
+    out["score_decode_us_per_image_1core_numpy"] = round(t_sd / 4 * 1e6, 1)
+    out["nms_us_per_image_1core"] = round(t_nms / 4 * 1e6, 1)
+    out["nms_candidates_per_image"] = round(ncand / 4, 1)
+    return out
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    run_rank(args)
 
 
 if __name__ == "__main__":

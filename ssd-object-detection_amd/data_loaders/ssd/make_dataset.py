@@ -25,14 +25,23 @@ class _SyntheticSplit:
     def __len__(self):
         return self.count
 
-    def __iter__(self):
+    def _sample(self, i):
+        cls, box = synth_gt(self.first + i)
+        return synth_image(self.first + i, self.size), cls, box
+
+    def lazy(self):
+        """One pass in iteration order as zero-argument callables: a consumer that keeps only a shard of the samples
+        (data-parallel ranks, models/ssd_model.py:get_train_set) pays for those only.  Same order on every rank."""
         order = np.arange(self.count)
         if self.shuffle:
             np.random.default_rng(977 + self._epoch).shuffle(order)
         self._epoch += 1
         for i in order:
-            cls, box = synth_gt(self.first + int(i))
-            yield synth_image(self.first + int(i), self.size), cls, box
+            yield lambda i=int(i): self._sample(i)
+
+    def __iter__(self):
+        for thunk in self.lazy():
+            yield thunk()
 
 
 class SSDDataLoader:

@@ -47,9 +47,26 @@ IMAGE_CHANNELS = 3
 
 
 class ParamTensor:
-    def __init__(self, name, shape, offset, index):
+    """One trainable variable of the reference (= one tf.clip_by_norm unit, models/ssd_model.py:249): `numel` elements at
+    `offset` of the flat buffers, alone in optimizer blocks block0 .. block0 + nblocks - 1 (the rest of them is zero)."""
+
+    def __init__(self, name, shape, offset, index, block0, nblocks):
         self.name, self.shape, self.offset, self.index = name, tuple(shape), offset, index
         self.numel = int(np.prod(shape))
+        self.block0, self.nblocks = block0, nblocks
+
+
+class FusedView:
+    """Two adjacent ParamTensors read as one array: the loc and conf filters of a level are separate Keras layers
+    (models/ssd_model.py:155-162: separate variables, separate clip norms) but one GEMM here.  The first part ends on a
+    block boundary and the second starts on it, so the pair is contiguous without sharing an optimizer block."""
+
+    def __init__(self, name, shape, parts):
+        self.name, self.shape, self.parts = name, tuple(shape), tuple(parts)
+        self.offset, self.index = parts[0].offset, parts[0].index
+        self.numel = int(np.prod(shape))
+        assert parts[1].offset == parts[0].offset + parts[0].numel and self.numel == parts[0].numel + parts[1].numel
+        self.indices = [p.index for p in parts]
 
 
 class SSDEngine:
@@ -97,11 +114,15 @@ class SSDEngine:
         self.tensors = []
         off = 0
 
-        def add(name, shape):
+        def add(name, shape, end_aligned=False):
             nonlocal off
-            t = ParamTensor(name, shape, off, len(self.tensors))
+            numel = int(np.prod(shape))
+            nb = (numel + self.block - 1) // self.block
+            start = off + (nb * self.block - numel if end_aligned else 0)
+            assert start % 8 == 0                 # 16-byte aligned in the bf16 copy too (DMA, float4)
+            t = ParamTensor(name, shape, start, len(self.tensors), off // self.block, nb)
             self.tensors.append(t)
-            off += (t.numel + self.block - 1) // self.block * self.block
+            off += nb * self.block
             return t
 
         self.conv_params = {}
@@ -112,8 +133,12 @@ class SSDEngine:
                                    add("conv%d/bias" % i, (nd["cout"],)))
         self.head_params = []
         for lvl, ((_, h, c), n) in enumerate(zip(self.fm, self.num_priors)):
-            nout = n * (4 + self.classes)      # loc filters (n*4) then conf filters (n*classes): one fused GEMM
-            self.head_params.append((add("head%d/kernel" % lvl, (nout, 3, 3, c)), add("head%d/bias" % lvl, (nout,))))
+            # loc filters (n*4) then conf filters (n*classes): one fused GEMM over two variables each (kernel, bias)
+            nl, nc = n * 4, n * self.classes
+            lk, ck = add("head%d/loc_kernel" % lvl, (nl, 3, 3, c), True), add("head%d/conf_kernel" % lvl, (nc, 3, 3, c))
+            lb, cb = add("head%d/loc_bias" % lvl, (nl,), True), add("head%d/conf_bias" % lvl, (nc,))
+            self.head_params.append((FusedView("head%d/kernel" % lvl, (nl + nc, 3, 3, c), (lk, ck)),
+                                     FusedView("head%d/bias" % lvl, (nl + nc,), (lb, cb))))
         self.n_flat = off
         self.n_params = sum(t.numel for t in self.tensors)
 
@@ -129,8 +154,7 @@ class SSDEngine:
         tbo = np.zeros(len(self.tensors) + 1, np.int32)
         bt = np.zeros(nb, np.int32)
         for i, t in enumerate(self.tensors):
-            b0 = t.offset // self.block
-            b1 = b0 + (t.numel + self.block - 1) // self.block
+            b0, b1 = t.block0, t.block0 + t.nblocks
             tbo[i], tbo[i + 1] = b0, b1
             bt[b0:b1] = i
         self.tensor_block_off = torch.from_numpy(tbo).to(dev)
@@ -160,14 +184,9 @@ class SSDEngine:
             if not t.name.endswith("kernel"):
                 continue
             cout, k, _, cin = t.shape
-            if t.name.startswith("head"):
-                lvl = int(t.name[4:t.name.index("/")])
-                n = self.num_priors[lvl]
-                parts = []
-                for rows in (n * 4, n * self.classes):          # two separate Keras layers (:155-162)
-                    lim = math.sqrt(6.0 / (k * k * cin + k * k * rows))
-                    parts.append(rng.uniform(-lim, lim, (rows, k, k, cin)))
-                w = np.concatenate(parts, 0)
+            if t.name.startswith("head"):                       # loc and conf: two separate Keras layers (:155-162)
+                lim = math.sqrt(6.0 / (k * k * cin + k * k * cout))
+                w = rng.uniform(-lim, lim, (cout, k, k, cin))
             else:
                 real_cin = IMAGE_CHANNELS if t.name == "conv0/kernel" else cin
                 lim = math.sqrt(6.0 / (k * k * real_cin + k * k * cout))
@@ -406,11 +425,11 @@ class SSDEngine:
                 for lvl in reversed(big):
                     head_wgrad(lvl, self._ws_side)
                     if on_ready:
-                        on_ready([t.index for t in self.head_params[lvl]])
+                        on_ready([i for t in self.head_params[lvl] for i in t.indices])
         for lvl in range(len(self.fm)):
             if lvl in big:
                 continue
-            on_side(lambda ws, lvl=lvl: head_wgrad(lvl, ws), [t.index for t in self.head_params[lvl]])
+            on_side(lambda ws, lvl=lvl: head_wgrad(lvl, ws), [i for t in self.head_params[lvl] for i in t.indices])
             head_dgrad(lvl, self._ws)
         opt_bucket(None)
         # trunk, last layer first
@@ -459,7 +478,7 @@ class SSDEngine:
             self._range_tables = {}
         tab = self._range_tables.get(key)
         if tab is None:
-            b0 = self.tensors[t0].offset // self.block
+            b0 = self.tensors[t0].block0
             tbo = (self.tensor_block_off[t0:t1 + 1] - b0).contiguous()
             bt = (self.block_tensor[b0:int(self.tensor_block_off[t1].item())] - t0).contiguous()
             tab = (b0, tbo, bt)

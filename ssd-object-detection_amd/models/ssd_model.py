@@ -21,7 +21,7 @@ import torch
 
 from .. import ops
 from ..engine import SSDEngine
-from ..parallel import GradReducer
+from ..parallel import GradReducer, shard_range
 from .. import optimizers as _opt
 from ..utils.scalar_log import ScalarLog
 
@@ -54,11 +54,14 @@ class SSDObjectDetectionModel:
             self.thresh = 0.5
 
     def __init__(self, classes, log_dir, device="cuda", seed=0, distributed=False, timestamp_dir=True):
+        self.distributed = bool(distributed)
         if timestamp_dir:
-            log_dir = os.path.join(log_dir, time.strftime("%Y-%m-%d-%H%M%S", time.localtime()))
+            stamp = [time.strftime("%Y-%m-%d-%H%M%S", time.localtime())]
+            if self.distributed and torch.distributed.is_initialized():
+                torch.distributed.broadcast_object_list(stamp, src=0)     # one run directory for all ranks (rank 0's clock)
+            log_dir = os.path.join(log_dir, stamp[0])
         self.cfg = SSDObjectDetectionModel.Config(classes, log_dir)
         self.device = torch.device(device)
-        self.distributed = bool(distributed)
         self._engine = SSDEngine(classes=self.cfg.classes, in_size=self.cfg.input_shape[0], device=device, seed=seed)
         self._pset = ops.build_priors(grids=self._engine.grids, device=device)
         assert self._pset.A == self._engine.A
@@ -85,21 +88,42 @@ class SSDObjectDetectionModel:
         return self._engine
 
     # ------------------------------------------------------------------ input pipeline (A8)
-    def get_train_set(self, dataset, batch_size=1):
+    def _rank_world(self):
+        if self.distributed and torch.distributed.is_initialized():
+            return torch.distributed.get_rank(), torch.distributed.get_world_size()
+        return 0, 1
+
+    def get_train_set(self, dataset, batch_size=1, shard=None):
         """Iterable of (image f32[B,300,300,3] in [-1,1], (cls i32[B,A], loc f32[B,A,4], mask u8[B,A])) device
-        batches; remainder dropped (reference :209-227: match_bbox -> apply_anchor_box -> (x-0.5)*2 -> batch)."""
+        batches; remainder dropped (reference :209-227: match_bbox -> apply_anchor_box -> (x-0.5)*2 -> batch).
+
+        Data parallel (`distributed=True`, or an explicit shard=(rank, world)): batch_size is the GLOBAL batch and the
+        iterable yields this rank's images of every global batch -- parallel.shard_range, positions
+        [rank*b/world, (rank+1)*b/world) -- so all ranks see the same number of batches (the same remainder is dropped)
+        and disjoint samples.  Samples of other ranks are skipped without being produced when the dataset offers
+        lazy() (an iterable of zero-argument callables, one per sample, in iteration order)."""
         model = self
+        rank, world = shard if shard is not None else self._rank_world()
+        assert batch_size % world == 0, "the global batch must divide evenly over the ranks"
+        lo, hi = shard_range(batch_size, rank, world)
 
         class _Batches:
             def __iter__(self_inner):
-                imgs, clss, boxes = [], [], []
-                for image, cls, box in dataset:
-                    imgs.append(np.asarray(image, np.float32))
-                    clss.append(np.asarray(cls, np.float32))
-                    boxes.append(np.asarray(box, np.float32))
-                    if len(imgs) == batch_size:
-                        yield model.make_batch(imgs, clss, boxes)
+                thunks = dataset.lazy() if hasattr(dataset, "lazy") else ((lambda s=s: s) for s in dataset)
+                mine, pos = [], 0
+                for thunk in thunks:
+                    if lo <= pos < hi:
+                        mine.append(thunk)
+                    pos += 1
+                    if pos == batch_size:
                         imgs, clss, boxes = [], [], []
+                        for t in mine:
+                            image, cls, box = t()
+                            imgs.append(np.asarray(image, np.float32))
+                            clss.append(np.asarray(cls, np.float32))
+                            boxes.append(np.asarray(box, np.float32))
+                        yield model.make_batch(imgs, clss, boxes)
+                        mine, pos = [], 0
 
         return _Batches()
 
@@ -126,7 +150,7 @@ class SSDObjectDetectionModel:
 
     def make_batch(self, images, cls_list, box_list):
         img = torch.from_numpy(np.stack(images, 0)).to(self.device, non_blocking=True)
-        img = (img - 0.5) * 2                          # reference :214 (exact in fp32)
+        img = (img - 0.5) * 2                          # reference :214 (exact in fp32); get_train_set's contract is f32
         gt = ops.pack_gt(box_list, cls_list, device=self.device)
         cls, loc, mask = ops.match_encode(*gt, self._pset, self.cfg.thresh)
         return img, (cls, loc, mask)
@@ -175,8 +199,8 @@ class SSDObjectDetectionModel:
         single = world == 1 and batch_step >= batch_size
         overlap = world > 1 and batch_step >= batch_size           # one micro-batch per rank: bucketed, overlapped reduce
         if overlap and self._reducer is None:
-            blocks = [(t.numel + eng.block - 1) // eng.block for t in eng.tensors]
-            self._reducer = GradReducer(eng.grad, [t.offset for t in eng.tensors], blocks, eng.block,
+            blocks = [t.nblocks for t in eng.tensors]
+            self._reducer = GradReducer(eng.grad, [t.block0 * eng.block for t in eng.tensors], blocks, eng.block,
                                         eng.clip_range_in_place)
         fused = single and isinstance(ssd_optimizer, _opt.Adam) and self.fused_optimizer
         fused_dp = overlap and isinstance(ssd_optimizer, _opt.Adam) and self.fused_optimizer
@@ -262,12 +286,32 @@ class SSDObjectDetectionModel:
         train_set, _val_set = data_loader.get_dataset()
         set_names, set_colors = data_loader.get_names_and_colors()
         batches = self.get_train_set(train_set, batch_size=cfg.batch_size)
+        self._assert_replicas_identical()
         self._scalars = ScalarLog(self.cfg.log_dir, self.device, distributed=self.distributed,
                                   console_interval=cfg.visualization_log_interval, logger=logger)
         try:
             self._train_loop(batches, set_names, set_colors, cfg)
-        finally:
-            self._scalars.close()
+        except BaseException:
+            self._scalars.close(collective=False)      # unwinding: the other ranks may not reach a collective
+            raise
+        self._scalars.close()
+
+    def _assert_replicas_identical(self):
+        """Data parallelism assumes every rank starts from the same weights and optimizer state (same seed / same
+        checkpoint): compare a checksum of the flat buffers across ranks before the first step."""
+        rank, world = self._rank_world()
+        if world == 1:
+            return
+        eng = self._engine
+        sums = torch.stack([eng.param.double().sum(), eng.param.double().abs().sum(), eng.adam_m.double().abs().sum(),
+                            eng.adam_v.double().sum(), torch.tensor(float(eng.step_count), dtype=torch.float64,
+                                                                    device=eng.param.device)])
+        lo, hi = sums.clone(), sums.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise RuntimeError("data-parallel replicas differ before training (checksums %s vs %s): same seed / "
+                               "checkpoint on every rank?" % (lo.tolist(), hi.tolist()))
 
     def _train_loop(self, batches, set_names, set_colors, cfg):
         if cfg.warmup and getattr(cfg, "start_epoch", 0) == 0:
@@ -310,7 +354,7 @@ class SSDObjectDetectionModel:
         try:
             self._train(data_loader, cfg)
         except Exception:
-            self.save("error_exit_save.pt")
+            self.save("error_exit_save.pt", collective=False)
             logger.critical("Error occurred while training, last model weight is saved to 'error_exit_save.pt'")
             raise
 
@@ -353,20 +397,26 @@ class SSDObjectDetectionModel:
         return coco_map(dets, gts, max_dets=max_dets)
 
     # ------------------------------------------------------------------ checkpoint
-    def save(self, path="model_weight.pt", extra=None):
+    def save(self, path="model_weight.pt", extra=None, collective=True):
         """Weights + Adam moments + step count (the reference's Keras .h5 has weights only, models/ssd_model.py:405-407);
-        `extra` (e.g. optimizer iteration counters, epoch) is stored alongside for resume."""
-        d = os.path.dirname(path)
-        if d:
-            os.makedirs(d, exist_ok=True)
-        sd = self._engine.state_dict()
-        if extra:
-            sd["extra"] = dict(extra)
-        torch.save(sd, path)
-        logger.info("Model is saved to %s", path)
+        `extra` (e.g. optimizer iteration counters, epoch) is stored alongside for resume.
+        Data parallel: the replicas are identical, rank 0 writes and the others wait for the file (collective=False on
+        error paths, where the other ranks may never arrive)."""
+        rank, world = self._rank_world()
+        if rank == 0:
+            d = os.path.dirname(path)
+            if d:
+                os.makedirs(d, exist_ok=True)
+            sd = self._engine.state_dict()
+            if extra:
+                sd["extra"] = dict(extra)
+            torch.save(sd, path)
+            logger.info("Model is saved to %s", path)
+        if world > 1 and collective:
+            torch.distributed.barrier()
 
     def load(self, path="model_weight.pt"):
-        sd = torch.load(path, map_location="cpu", weights_only=False)
+        sd = torch.load(path, map_location="cpu", weights_only=True)     # tensors, lists, ints and strings only
         self._engine.load_state_dict(sd)
         self._slot_owner = _RESTORED
         logger.info("Model is loaded from %s", path)

@@ -50,12 +50,27 @@ class GradReducer:
         self.buckets = make_buckets(self.blocks, max(1, (total + n_buckets - 1) // n_buckets))
         self.use_streams = flat_grad.is_cuda
         self.comm = torch.cuda.Stream() if self.use_streams else None
+        self.profile = False                  # True: events around every bucket's exchange (bucket_times_ms)
+        self._events = []
         self.begin()
 
     def begin(self):
         self.ready = [False] * len(self.offsets)
         self.next_bucket = 0
         self.handles = []
+        self._events = []
+
+    def _mark_done(self, k):
+        if self.profile and k < len(self._events):
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(self.comm)
+            self._events[k][1] = e1
+
+    def bucket_times_ms(self):
+        """Per bucket of the last step (profile=True): time from 'clipped, all-reduce enqueued' to 'all-reduce complete'
+        on the communication stream -- includes waiting behind the previous bucket's exchange."""
+        torch.cuda.synchronize()
+        return [e0.elapsed_time(e1) for e0, e1 in self._events if e1 is not None]
 
     def _range(self, t0, t1):
         start = self.offsets[t0]
@@ -81,6 +96,10 @@ class GradReducer:
             with torch.cuda.stream(self.comm):
                 self.comm.wait_event(ev)
                 self.clip_fn(t0, t1)
+                if self.profile:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record(self.comm)
+                    self._events.append([e0, None])
                 self.handles.append(dist.all_reduce(view, group=self.group, async_op=True))
         else:
             self.clip_fn(t0, t1)
@@ -96,14 +115,20 @@ class GradReducer:
             ev.record()                                   # the caller's stream: the whole backward pass is enqueued
             with torch.cuda.stream(self.comm):
                 self.comm.wait_event(ev)
-                for h, (t0, t1) in zip(self.handles, self.buckets):
+                for k, (h, (t0, t1)) in enumerate(zip(self.handles, self.buckets)):
                     h.wait()
+                    self._mark_done(k)
                     post_fn(t0, t1)
             torch.cuda.current_stream().wait_stream(self.comm)
             self.handles = []
             return
-        for h, (t0, t1) in zip(self.handles, self.buckets):
-            h.wait()
+        for k, (h, (t0, t1)) in enumerate(zip(self.handles, self.buckets)):
+            if self.use_streams:
+                with torch.cuda.stream(self.comm):
+                    h.wait()
+                    self._mark_done(k)
+            else:
+                h.wait()
             if post_fn is not None:
                 post_fn(t0, t1)
         if self.use_streams:

@@ -1,9 +1,13 @@
 """Entry point with the reference's command line: `python tools/train.py <config.yml>` (reference tools/train.py:
-73-81) and the same YAML schema (config/default.yml of the reference; read at :23-69).
+73-81) and the same YAML schema (config/default.yml of the reference; keys read at :23-69).
 
 Run from the repository root as
     python -m ssd_object_detection_amd.tools.train ssd-object-detection_amd/config/default.yml
-Multi-GPU (one process per GPU, RCCL):  python -m torch.distributed.run --nproc-per-node N -m ... train <cfg>"""
+Data parallel (one process per GPU, RCCL over xGMI):
+    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 -m ssd_object_detection_amd.tools.train <cfg>
+`model.train.batch_size` is then the GLOBAL batch: rank r trains on its image shard of every batch (one micro-batch
+of the reference's split_batch loop per rank, models/ssd_model.py:240-256), one log directory is shared, and only rank 0
+writes config.json and checkpoints."""
 import argparse
 import json
 import logging
@@ -13,50 +17,76 @@ import yaml
 
 logger = logging.getLogger(__name__)
 
+# TrainConfig field  <-  path into the YAML document (the reference's schema, config/default.yml:17-41)
+TRAIN_CONFIG_KEYS = {
+    "epoch": "model/train/epoch",
+    "batch_size": "model/train/batch_size",
+    "warmup": "model/warmup/enable",
+    "warmup_step": "model/warmup/step",
+    "visualization_log_interval": "model/log_interval",
+    "split_batch": "model/split_train/enable",
+    "split_batch_size": "model/split_train/batch_size",
+}
+
 
 def load_config(yaml_file):
     with open(yaml_file, "r") as f:
         return yaml.safe_load(f)
 
 
+def cfg_get(config, path):
+    node = config
+    for key in path.split("/"):
+        node = node[key]
+    return node
+
+
 def _make_optimizer(section, schedule):
     from .. import optimizers
-    name = section["name"].lower()
-    if name == "adam":
-        return optimizers.Adam(schedule, **section)
-    if name == "sgd":
-        return optimizers.SGD(schedule, **section)
-    raise ValueError
+    kinds = {"adam": optimizers.Adam, "sgd": optimizers.SGD}
+    kind = kinds.get(section["name"].lower())
+    if kind is None:
+        raise ValueError                     # reference tools/train.py:47,53
+    return kind(schedule, **section)
+
+
+def _init_distributed():
+    """(rank, world); joins the process group when launched under torch.distributed.run."""
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1
+    backend = os.environ.get("SSD_DIST_BACKEND", "nccl")
+    if torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+    if not torch.distributed.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group(backend)
+    return torch.distributed.get_rank(), torch.distributed.get_world_size()
 
 
 def train(config):
-    import torch
     from .. import optimizers
     from ..data_loaders import SSDDataLoader
     from ..models import SSDObjectDetectionModel
 
-    distributed = int(os.environ.get("WORLD_SIZE", "1")) > 1
-    if distributed:
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        torch.distributed.init_process_group(os.environ.get("SSD_DIST_BACKEND", "nccl"))
-    data = SSDDataLoader(dataset_root=config["data"]["dataset_root"], shuffle=config["data"]["shuffle"],
-                         dataset=config["data"]["dataset"],
-                         mini_batch=config["data"]["mini_batch"]["num_data"] if config["data"]["mini_batch"]["enable"] else 0)
-    model = SSDObjectDetectionModel(classes=config["data"]["num_classes"], log_dir=config["model"]["log_dir"],
-                                    distributed=distributed)
-    lr_scheduler = optimizers.ExponentialDecay(initial_learning_rate=config["model"]["train"]["lr"]["initial"],
-                                               decay_steps=config["model"]["train"]["lr"]["decay_step"],
-                                               decay_rate=config["model"]["train"]["lr"]["decay_rate"])
-    warmup_lr_scheduler = optimizers.PolynomialDecay(initial_learning_rate=config["model"]["warmup"]["lr"]["start"],
-                                                     decay_steps=config["model"]["warmup"]["step"],
-                                                     end_learning_rate=config["model"]["warmup"]["lr"]["end"])
-    optimizer = _make_optimizer(config["model"]["train"]["optimizer"], lr_scheduler)
-    warmup_optimizer = _make_optimizer(config["model"]["warmup"]["optimizer"], warmup_lr_scheduler)
+    rank, world = _init_distributed()
+    data_cfg, model_cfg = config["data"], config["model"]
+    subset = data_cfg["mini_batch"]
+    data = SSDDataLoader(dataset_root=data_cfg["dataset_root"], dataset=data_cfg["dataset"], shuffle=data_cfg["shuffle"],
+                         mini_batch=subset["num_data"] if subset["enable"] else 0)
+    model = SSDObjectDetectionModel(classes=data_cfg["num_classes"], log_dir=model_cfg["log_dir"], distributed=world > 1)
+
+    lr, wlr = model_cfg["train"]["lr"], model_cfg["warmup"]["lr"]
+    optimizer = _make_optimizer(model_cfg["train"]["optimizer"],
+                                optimizers.ExponentialDecay(lr["initial"], lr["decay_step"], lr["decay_rate"]))
+    warmup_optimizer = _make_optimizer(model_cfg["warmup"]["optimizer"],
+                                       optimizers.PolynomialDecay(wlr["start"], model_cfg["warmup"]["step"], wlr["end"]))
 
     # resume (SURVEY.md 8f, N3; the reference has load() but no resume path): `model.resume: <checkpoint>` in the YAML
     # restores weights, Adam moments, step counters and continues with the epoch after the saved one
     start_epoch = 0
-    resume = config["model"].get("resume")
+    resume = model_cfg.get("resume")
     if resume:
         extra = model.load(resume)
         optimizer.iterations = int(extra.get("iterations", model.get_engine().step_count))
@@ -64,22 +94,16 @@ def train(config):
         start_epoch = int(extra.get("epoch", 0))
         logger.info("Resuming from %s at epoch %d (optimizer step %d)", resume, start_epoch, optimizer.iterations)
 
-    os.makedirs(model.get_log_dir(), exist_ok=True)
-    with open(os.path.join(model.get_log_dir(), "config.json"), "w") as f:
-        json.dump(config, f, sort_keys=True, indent=4, separators=(',', ':'))
+    if rank == 0:                            # the run's configuration next to its logs (reference tools/train.py:55-56)
+        os.makedirs(model.get_log_dir(), exist_ok=True)
+        text = json.dumps(config, sort_keys=True, indent=4, separators=(",", ":"))
+        with open(os.path.join(model.get_log_dir(), "config.json"), "w") as f:
+            f.write(text)
 
-    model.train(data_loader=data,
-                cfg=SSDObjectDetectionModel.TrainConfig(epoch=config["model"]["train"]["epoch"],
-                                                        batch_size=config["model"]["train"]["batch_size"],
-                                                        optimizer=optimizer,
-                                                        warmup=config["model"]["warmup"]["enable"],
-                                                        warmup_optimizer=warmup_optimizer,
-                                                        warmup_step=config["model"]["warmup"]["step"],
-                                                        visualization_log_interval=config["model"]["log_interval"],
-                                                        split_batch=config["model"]["split_train"]["enable"],
-                                                        split_batch_size=config["model"]["split_train"]["batch_size"],
-                                                        start_epoch=start_epoch))
-    model.save(os.path.join(model.get_log_dir(), config["model"]["save"]))
+    fields = {name: cfg_get(config, path) for name, path in TRAIN_CONFIG_KEYS.items()}
+    fields.update(optimizer=optimizer, warmup_optimizer=warmup_optimizer, start_epoch=start_epoch)
+    model.train(data_loader=data, cfg=SSDObjectDetectionModel.TrainConfig(**fields))
+    model.save(os.path.join(model.get_log_dir(), model_cfg["save"]))      # rank 0 writes; the others wait
     return model
 
 

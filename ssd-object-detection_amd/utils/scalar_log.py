@@ -21,6 +21,11 @@ class HardNegativeThresholdError(AssertionError):
     """status == 2 in a logged row: the hard-negative threshold reached 0 (reference assert, models/ssd_model.py:375)."""
 
 
+class NoPositivesError(ValueError):
+    """status == 1 in a logged row: no positive anchor in the (micro-)batch, or 3P exceeds the anchor count -- the
+    reference's tf.math.top_k / division would raise at that step (models/ssd_model.py:359,368)."""
+
+
 class ScalarLog:
     def __init__(self, log_dir, device, capacity=512, distributed=False, console_interval=10, logger=None):
         self.path = os.path.join(log_dir, "scalars.jsonl")
@@ -40,19 +45,24 @@ class ScalarLog:
         if len(self.meta) == self.capacity:
             self.flush()
 
-    def flush(self):
-        """One device->host transfer for everything recorded since the last flush; returns the rows written."""
+    def flush(self, collective=True):
+        """One device->host transfer for everything recorded since the last flush; returns the rows written.
+        A row whose status word is not 0 raises here -- up to `capacity` steps (or one epoch) after the step itself: the
+        price of not reading the device every step; the updates in between have been applied (and a step with status 1
+        moved the weights on stale Adam momentum only: its gradient is zero)."""
         n = len(self.meta)
         if n == 0:
             return []
         block = self.ring[:n]
-        if self.distributed and torch.distributed.is_initialized():
-            # losses: mean over ranks (each rank logged its own image shard); status: any rank failing counts
+        if collective and self.distributed and torch.distributed.is_initialized():
+            # losses: mean over ranks (each rank logged its own image shard); status: the worst of any rank counts
             block = block.clone()
-            block[:, 7] = (block[:, 7] == 2).float()
+            status = block[:, 7].clone()
+            block[:, 7] = 0
             torch.distributed.all_reduce(block)
+            torch.distributed.all_reduce(status, op=torch.distributed.ReduceOp.MAX)
             block[:, :7] /= torch.distributed.get_world_size()
-            block[:, 7] = torch.where(block[:, 7] > 0, 2.0, 0.0)
+            block[:, 7] = status
         host = block.cpu().numpy()                       # the only host sync
         rows = []
         write = (not self.distributed) or (not torch.distributed.is_initialized()) or torch.distributed.get_rank() == 0
@@ -72,15 +82,21 @@ class ScalarLog:
             self._file.flush()
         self.rows_written += n
         self.meta.clear()
-        bad = [m for m, r in zip(rows, host) if r[7] == 2]
+        bad = [(m, int(r[7])) for m, r in zip(rows, host) if r[7] != 0]
         if bad:
-            raise HardNegativeThresholdError("hard-negative threshold reached 0 at %s step %d "
-                                             "(reference assert, models/ssd_model.py:375)" % (bad[0][0], bad[0][1]))
+            (stage, step, _), status = bad[0]
+            if status == 2:
+                raise HardNegativeThresholdError("hard-negative threshold reached 0 at %s step %d "
+                                                 "(reference assert, models/ssd_model.py:375)" % (stage, step))
+            raise NoPositivesError("no positive anchors (or 3P > anchors) at %s step %d: the reference's top_k / division "
+                                   "raises there (models/ssd_model.py:359,368)" % (stage, step))
         return rows
 
-    def close(self):
+    def close(self, collective=True):
+        """collective=False while unwinding from an exception: a rank that failed alone must not enter an all-reduce the
+        others never reach (its rows are written from local values)."""
         try:
-            self.flush()
+            self.flush(collective=collective)
         finally:
             if self._file is not None:
                 self._file.close()

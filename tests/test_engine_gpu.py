@@ -23,11 +23,39 @@ def engine():
     return SSDEngine(classes=81, seed=3)
 
 
+def gemm_arrays(engine):
+    """The arrays the network computes with, by name: conv{i}/kernel|bias and the per-level fused head{l}/kernel|bias
+    ([loc filters ; conf filters], one GEMM) -- NOT the clip/optimizer partition (engine.tensors)."""
+    out = [t for i in sorted(engine.conv_params) for t in engine.conv_params[i]]
+    return out + [t for pair in engine.head_params for t in pair]
+
+
+def reference_variables(engine):
+    """The reference's trainable variables as (name, flat offset, numel), built from its layer list and NOT from
+    engine.tensors: one kernel + one bias per Conv2D of models/ssd_model.py:77-151 (20 layers) and, per feature level,
+    a loc Conv2D and a conf Conv2D with kernel + bias each (:155-162) -> 64 variables, each clipped on its own (:249).
+    Locations come from the GEMM layout: rows [0, 4n) of a level's fused filter array are the loc layer's."""
+    from ssd_object_detection_amd.engine import SSD300_TRUNK, SSD300_NUM_PRIORS
+    out = []
+    for i, (kind, cin, cout, k, _, _, _) in enumerate(SSD300_TRUNK):
+        if kind != "conv":
+            continue
+        wt, bt = engine.conv_params[i]
+        out += [("conv%d/kernel" % i, wt.offset, cout * k * k * cin), ("conv%d/bias" % i, bt.offset, cout)]
+    for lvl, n in enumerate(SSD300_NUM_PRIORS):
+        wt, bt = engine.head_params[lvl]
+        c = wt.shape[-1]
+        nl, nc = n * 4, n * engine.classes
+        out += [("loc%d/kernel" % lvl, wt.offset, nl * 9 * c), ("loc%d/bias" % lvl, bt.offset, nl),
+                ("conf%d/kernel" % lvl, wt.offset + nl * 9 * c, nc * 9 * c), ("conf%d/bias" % lvl, bt.offset + nl, nc)]
+    return out
+
+
 def oracle_params(engine, requires_grad=False):
     p = {}
     host = engine.param_bf16.float().cpu()
     host_f32 = engine.param.cpu()
-    for t in engine.tensors:
+    for t in gemm_arrays(engine):
         src = host if t.name.endswith("kernel") else host_f32          # biases are applied in fp32
         p[t.name] = src[t.offset:t.offset + t.numel].view(t.shape).clone().requires_grad_(requires_grad)
     return p
@@ -38,6 +66,14 @@ def test_static_plan(engine):
     assert engine.grids == ((38, 38), (19, 19), (10, 10), (5, 5), (3, 3), (1, 1))
     # 25 128 118 parameters in the reference + the 5 zero-padded input channels of conv0
     assert engine.n_params == 25128118 + 64 * 3 * 3 * 5
+    # the clip / optimizer partition is the reference's variable list: 64 tensors (models/ssd_model.py:155-162, :249)
+    ref = reference_variables(engine)
+    assert len(engine.tensors) == len(ref) == 64
+    assert sorted((t.offset, t.numel) for t in engine.tensors) == sorted((o, n) for _, o, n in ref)
+    bt = engine.block_tensor.cpu().numpy()
+    for t in engine.tensors:                                           # every optimizer block belongs to one variable
+        b0, b1 = t.offset // engine.block, (t.offset + t.numel - 1) // engine.block + 1
+        assert (bt[b0:b1] == t.index).all() and (bt == t.index).sum() == b1 - b0
 
 
 def test_forward_backward_vs_oracle(engine):
@@ -60,7 +96,7 @@ def test_forward_backward_vs_oracle(engine):
     (loc_r * dloc.float()).sum().add((conf_r * dconf.float()).sum()).backward()
     gflat = engine.grad.cpu()
     worst = 0.0
-    for t in engine.tensors:
+    for t in gemm_arrays(engine):
         got = gflat[t.offset:t.offset + t.numel].view(t.shape)
         want = params[t.name].grad
         if t.name == "conv0/kernel":
@@ -108,34 +144,64 @@ def test_two_stream_schedule_is_bitwise_neutral(engine):
 
 
 def test_optimizer_vs_oracle(engine):
-    """clip_by_norm per tensor + Adam on the flat buffer vs the numpy oracle (Keras formulas)."""
+    """clip_by_norm per variable + Adam on the flat buffer vs the numpy oracle (Keras formulas), with the oracle's
+    partition taken from the reference's layer list (reference_variables), not from the engine's own table."""
     g = torch.Generator().manual_seed(2)
     engine.init_params(seed=3)
     p0 = engine.param.cpu().numpy().copy()
     grad = torch.zeros(engine.n_flat)
-    for i, t in enumerate(engine.tensors):
-        scale = 10.0 ** (-(i % 5))                                    # some tensors above, some below the 0.01 clip norm
-        grad[t.offset:t.offset + t.numel] = torch.randn(t.numel, generator=g) * scale / math.sqrt(t.numel)
+    ref = reference_variables(engine)
+    for i, (name, off, numel) in enumerate(ref):
+        scale = 10.0 ** (-(i % 5))                                    # some variables above, some below the 0.01 clip norm
+        grad[off:off + numel] = torch.randn(numel, generator=g) * scale / math.sqrt(numel)
     engine.grad.copy_(grad)
     engine.clip_scales(0.01)
+    by_offset = {t.offset: t.index for t in engine.tensors}
     norms = engine.grad_norms.cpu().numpy()
     scales = engine.clip_scale.cpu().numpy()
     m = np.zeros_like(p0); v = np.zeros_like(p0); p = p0.astype(np.float64)
     gnp = grad.numpy().astype(np.float64)
     for step in (1, 2):
         engine.adam(1e-3, engine.grad, grad_scale=0.5, use_clip_scale=True)
-        for i, t in enumerate(engine.tensors):
-            sl = slice(t.offset, t.offset + t.numel)
+        for name, off, numel in ref:
+            sl = slice(off, off + numel)
             gt = gnp[sl]
-            assert abs(norms[i] - np.linalg.norm(gt)) <= 1e-5 * np.linalg.norm(gt)
+            i = by_offset[off]
+            assert abs(norms[i] - np.linalg.norm(gt)) <= 1e-5 * np.linalg.norm(gt), name
             clipped = O.clip_by_norm(gt, 0.01) * 0.5
-            assert abs(scales[i] - 0.01 / max(np.linalg.norm(gt), 0.01)) < 1e-5
+            assert abs(scales[i] - 0.01 / max(np.linalg.norm(gt), 0.01)) < 1e-5, name
             p[sl], m_, v_ = O.adam_step(p[sl], clipped, m[sl], v[sl], step, 1e-3)
             m[sl], v[sl] = m_, v_
         got = engine.param.cpu().numpy()
         assert np.abs(got - p).max() <= 2e-6, step
     bf = engine.param_bf16.float().cpu().numpy()
     assert np.abs(bf - got).max() <= 2 ** -8 * np.abs(got).max()
+    engine.init_params(seed=3)
+
+
+def test_loc_and_conf_heads_are_clipped_separately(engine):
+    """||g_loc|| << ||g_conf|| on every level: the reference clips the loc and conf layers' variables on their own
+    (models/ssd_model.py:155-162, :249), so BOTH come out at norm 0.01 -- clipping their concatenation would leave the loc
+    part far below it.  Checked on the in-place clip (the data-parallel path) and on the micro-batch accumulation."""
+    engine.grad.zero_()
+    g = torch.Generator().manual_seed(9)
+    ref = [r for r in reference_variables(engine) if r[0].startswith(("loc", "conf"))]
+    for name, off, numel in ref:
+        target = 0.05 if name.startswith("loc") else 50.0                 # both above the clip norm, 1000x apart
+        v = torch.randn(numel, generator=g)
+        engine.grad[off:off + numel] = (v * (target / v.norm())).cuda()
+    g0 = engine.grad.clone()
+    engine.clip_scales(0.01)
+    engine.accumulate_clipped(first=True)
+    t0 = engine.head_params[0][0].index
+    engine.clip_range_in_place(t0, len(engine.tensors), 0.01)
+    torch.cuda.synchronize()
+    for buf in (engine.grad, engine.grad_acc):
+        for name, off, numel in ref:
+            nrm = float(buf[off:off + numel].double().norm())
+            assert abs(nrm - 0.01) < 1e-6, (name, nrm)
+    assert torch.equal(engine.grad, engine.grad_acc)
+    engine.grad.copy_(g0)
     engine.init_params(seed=3)
 
 

@@ -78,3 +78,30 @@ def test_rank_mean_world2(tmp_path):
         np.testing.assert_allclose(vals[:3], (1.5, 2.0 * step, 0.5 + 0.5 * step), rtol=1e-6)
     got = SL.read_scalars(str(tmp_path / "scalars.jsonl"))         # rank 0 alone writes the file
     assert len(got["train/loss"]) == 2
+
+
+def test_status_1_is_an_error_too(tmp_path):
+    """No positives in a step (status 1): the reference's top_k / division raises at that step (models/ssd_model.py:359,368);
+    here it surfaces at the read, with its own exception type, after the rows are on disk."""
+    log = SL.ScalarLog(str(tmp_path), "cpu", capacity=8)
+    log.record("warmup", 1, row(1, 1, 1), 1e-3)
+    log.record("warmup", 2, row(0, 0, 0, status=1.0), 1e-3)
+    with pytest.raises(SL.NoPositivesError, match="step 2"):
+        log.flush()
+    assert len(SL.read_scalars(log.path)["warmup/loss"]) == 2
+    log.close()
+
+
+def test_close_without_collective_does_not_touch_the_process_group(tmp_path, monkeypatch):
+    """Unwinding from an exception on one rank: close(collective=False) must write local rows without an all-reduce."""
+    log = SL.ScalarLog(str(tmp_path), "cpu", capacity=8, distributed=True)
+    log.record("train", 1, row(1, 2, 3), 1e-3)
+    monkeypatch.setattr(torch.distributed, "is_initialized", lambda: True)
+    monkeypatch.setattr(torch.distributed, "get_rank", lambda: 0)
+
+    def boom(*a, **k):
+        raise AssertionError("collective entered")
+
+    monkeypatch.setattr(torch.distributed, "all_reduce", boom)
+    log.close(collective=False)
+    assert SL.read_scalars(log.path)["train/loss"] == [(1, 6.0)]

@@ -124,12 +124,21 @@ def pmc_profile(name):
     return (json.load(open(files[-1])), os.path.basename(files[-1])) if files else (None, None)
 
 
-def nms_inputs(torch, B, A, dtype, seed=7):
-    """SURVEY.md 8(d) NMS input: logits N(0,1) with the background logit +4, box offsets N(0, 0.5)."""
+def nms_inputs(torch, B, A, dtype, seed=7, n_hot=320):
+    """SURVEY.md 8(d) NMS input: logits N(0,1) with the background logit +4 (background-dominated, as a trained detector's
+    are) and, so that ~200-400 candidates per image survive score 0.3 and neighbouring priors fire on the same class,
+    n_hot/8 clusters per image of 8 anchors within a 40-anchor window boosted by U(7,11) on one class (the construction of
+    tests/test_detect_gpu.py:synth_logits); box offsets N(0, 0.2)."""
     g = torch.Generator(device="cuda").manual_seed(seed)
     conf = torch.randn((B, A, 81), generator=g, device="cuda")
     conf[..., 80] += 4.0
-    loc = torch.randn((B, A, 4), generator=g, device="cuda") * 0.5
+    nc = max(1, n_hot // 8)
+    centre = torch.randint(0, A - 40, (B, nc, 1), generator=g, device="cuda")
+    idx = (centre + torch.randint(0, 40, (B, nc, 8), generator=g, device="cuda")).reshape(B, -1)
+    k = torch.randint(0, 80, (B, nc, 1), generator=g, device="cuda").expand(B, nc, 8).reshape(B, -1)
+    boost = torch.rand((B, nc * 8), generator=g, device="cuda") * 4.0 + 7.0
+    conf[torch.arange(B, device="cuda")[:, None], idx, k] += boost
+    loc = torch.randn((B, A, 4), generator=g, device="cuda") * 0.2
     return conf.to(dtype).contiguous(), loc.to(dtype).contiguous()
 
 
@@ -486,7 +495,10 @@ def cpu_baseline(np, torch):
     r2 = np.random.default_rng(7)
     conf = r2.standard_normal((4, 8732, 81)).astype(np.float32)
     conf[..., 80] += 4.0
-    loc = (r2.standard_normal((4, 8732, 4)) * 0.5).astype(np.float32)
+    for b in range(4):                                    # the hot clusters of nms_inputs()
+        for c0 in r2.integers(0, 8732 - 40, 40):
+            conf[b, c0 + r2.integers(0, 40, 8), int(r2.integers(0, 80))] += r2.uniform(7, 11, 8).astype(np.float32)
+    loc = (r2.standard_normal((4, 8732, 4)) * 0.2).astype(np.float32)
     t_sd = t_nms = 0.0
     ncand = 0
     for i in range(4):

@@ -9,8 +9,11 @@
  * Conventions
  *   - extern "C", plain pointers and sizes, no torch / C++ types.
  *   - Unless a parameter says HOST, every pointer is a DEVICE pointer owned by the caller.
- *     The library allocates nothing, keeps no mutable global state and creates no streams;
- *     scratch is passed as (ws, ws_bytes) sized by the matching *_workspace_bytes().
+ *     The library allocates nothing, creates no streams, reads no environment variables and keeps no state that
+ *     a result depends on: calls are re-entrant and thread-safe.  (Its only process-wide state: the idempotent
+ *     once-per-device registration of kernels that need > 64 KB of LDS, and the development overrides of
+ *     ssd_dev_knob at the end of this header, which the product never sets.)
+ *     Scratch is passed as (ws, ws_bytes) sized by the matching *_workspace_bytes().
  *   - `stream` (last argument) is a hipStream_t passed as void*; all work is enqueued on it
  *     and nothing synchronises the host, so every call can be captured into a hipGraph.
  *   - Return value: SSD_OK (0) or a negative ssd_status.  Kernels never abort.  The Python
@@ -251,9 +254,41 @@ int ssd_adam_step(float* param, const float* grad, float* m, float* v, void* par
 int ssd_sgd_step(float* param, const float* grad, void* param_bf16, long long n, const int32_t* block_tensor,
                  const float* scale, float grad_scale, float lr, void* stream);
 
-/* Development only (no reference counterpart): override one of the library's tuning knobs (the SSD_* environment
- * variables documented in DESIGN.md, e.g. "SSD_CONV_VARIANT") at run time, for A/B timing of kernel variants inside one
- * process.  Results never depend on a knob; SSD_ERR_VALUE for an unknown name. */
+/* ------------------------------------------------------------------------------------------
+ * Dispatch queries (no reference counterpart; testing / reports): which kernel a convolution call with this shape
+ * resolves to.  They run the library's own dispatch code with launching switched off, so the answer cannot drift from
+ * what the call does.  Return: a plan word >= 0 (kernel id in SSD_PLAN_KERNEL_MASK, path flags above it) or a negative
+ * ssd_status for a shape the call itself would reject.  pool: 0 = ssd_conv2d_fwd, 1 = ssd_conv2d_fwd_pool, 2 = the same
+ * with y == NULL.  ws_bytes: the workspace the call would be given (0: none, no split-K).
+ * ---------------------------------------------------------------------------------------- */
+enum ssd_conv_plan {
+    SSD_PLAN_KERNEL_MASK = 0xff,
+    SSD_PLAN_C64B = 1, SSD_PLAN_C64, SSD_PLAN_P32_64, SSD_PLAN_P32_128, SSD_PLAN_PATCH_64, SSD_PLAN_PATCH_128, SSD_PLAN_8PH,
+    SSD_PLAN_DMA_256_256, SSD_PLAN_DMA_256_128, SSD_PLAN_DMA_256_64, SSD_PLAN_DMA_128_64, SSD_PLAN_DMA_128_128,
+    SSD_PLAN_REG_64, SSD_PLAN_REG_128, SSD_PLAN_CONV0_FWD, SSD_PLAN_PW,
+    SSD_PLAN_WG_FIRST = 32, SSD_PLAN_WG_PATCH_16x16, SSD_PLAN_WG_PATCH_6x40, SSD_PLAN_WG_PATCH_10x24, SSD_PLAN_WG_TILE,
+    SSD_PLAN_WG_GENERIC, SSD_PLAN_WG_DMA,
+    SSD_PLAN_F_FLAT = 0x100,         /* strip blocks over a narrow map */
+    SSD_PLAN_F_ROWFLAT = 0x200,      /* one strip of rows over all images */
+    SSD_PLAN_F_SPLITK = 0x400,       /* split-K partial sums + k_igemm_finalize */
+    SSD_PLAN_F_POOL_FUSED = 0x800,   /* 2x2 pooling computed in the convolution's epilogue */
+    SSD_PLAN_F_S2 = 0x1000,          /* stride-2 data gradient by parity classes */
+    SSD_PLAN_F_REDUCE_WIDE = 0x2000  /* >= 32 weight-gradient splits: k_wgrad_reduce_wide (else k_wgrad_reduce2) */
+};
+int ssd_conv2d_fwd_plan(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo,
+                        int pool, size_t ws_bytes);
+int ssd_conv2d_head_fwd_plan(int B, int H, int W, int Cin, int per_cell, int classes, size_t ws_bytes);
+int ssd_conv2d_bwd_data_plan(int B, int H, int W, int Cin, int Cout_pad, int ksize, int stride, int pad_t, int pad_l, int Ho,
+                             int Wo, int accumulate, size_t ws_bytes);
+int ssd_conv2d_bwd_weight_plan(int B, int H, int W, int Cin, int Cout, int ldy, int ksize, int stride, int pad_t, int pad_l,
+                               int Ho, int Wo);
+const char* ssd_conv_plan_name(int plan);
+
+/* Development only (no reference counterpart): override one of the library's kernel-selection defaults (names in DESIGN.md
+ * section 4, e.g. "SSD_CONV_TILE") for A/B timing of kernel variants or to force a dispatch path in a test, inside one
+ * process.  This is the ONE piece of mutable state the library has besides the once-per-device registration of large-LDS
+ * kernels: relaxed atomics, never set by the product, never read from the environment, and results never depend on it (every
+ * variant computes the same convolution).  SSD_ERR_VALUE for an unknown name. */
 int ssd_dev_knob(const char* name, int value);
 
 #ifdef __cplusplus

@@ -59,6 +59,11 @@ _SIGNATURES = {
     "ssd_adam_step": (ctypes.c_int, [VP, VP, VP, VP, VP, ctypes.c_longlong, VP, VP] + [ctypes.c_float] * 5 + [VP]),
     "ssd_sgd_step": (ctypes.c_int, [VP, VP, VP, ctypes.c_longlong, VP, VP, ctypes.c_float, ctypes.c_float, VP]),
     "ssd_dev_knob": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
+    "ssd_conv2d_fwd_plan": (ctypes.c_int, [ctypes.c_int] * 12 + [ctypes.c_size_t]),
+    "ssd_conv2d_head_fwd_plan": (ctypes.c_int, [ctypes.c_int] * 6 + [ctypes.c_size_t]),
+    "ssd_conv2d_bwd_data_plan": (ctypes.c_int, [ctypes.c_int] * 12 + [ctypes.c_size_t]),
+    "ssd_conv2d_bwd_weight_plan": (ctypes.c_int, [ctypes.c_int] * 12),
+    "ssd_conv_plan_name": (ctypes.c_char_p, [ctypes.c_int]),
     "ssd_loss_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "ssd_loss_fwd_bwd": (ctypes.c_int, [VP, VP, ctypes.c_int, VP, VP, VP, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_float, VP, VP, VP, VP, ctypes.c_size_t, VP]),

@@ -23,6 +23,9 @@
 //                  (grid.z); fp32 partial slabs are summed in fixed order (deterministic) by
 //                  k_wgrad_reduce.  The bias gradient rides along as an extra MFMA against a B fragment
 //                  of ones.
+#include <atomic>
+#include <climits>
+#include <cstdint>
 #include <cstring>
 #include <type_traits>
 #include "common.h"
@@ -3017,12 +3020,19 @@ __global__ void k_head_grad_pack(const bf16_raw* __restrict__ dloc, const bf16_r
                    (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16));
 }
 
-// Development knobs: read from the environment on first use, overridable at run time through ssd_dev_knob (A/B timing
-// of kernel variants inside one process).  Production code never sets them.
-struct Knob { const char* name; int value; bool init; };
-Knob g_knobs[] = {{"SSD_ABLATE", 0, false}, {"SSD_DGRAD_S2", 0, false}, {"SSD_CONV_VARIANT", 0, false}, {"SSD_CONV_PATCH", 0, false},
-                  {"SSD_CONV_TILE", 0, false}, {"SSD_SPLITK", 0, false}, {"SSD_WGRAD_DMA", 0, false}, {"SSD_WGRAD_PATCH", 0, false},
-                  {"SSD_WGRAD_PATCH_SINGLE", 0, false}, {"SSD_WGRAD_PATCH_SHAPE", 0, false}, {"SSD_WGRAD_TILE", 0, false}, {"SSD_CONV_PATCH_FORM", 0, false}, {"SSD_CONV_PATCH_FLAT", 0, false}, {"SSD_WGRAD_FIRST", 0, false}, {"SSD_CONV_FIRST", 0, false}, {"SSD_WGRAD_PATCH_XCD", 0, false}, {"SSD_CONV_C64", 0, false}, {"SSD_CONV_POOL_FUSE", 0, false}, {"SSD_CONV_PATCH_ROWFLAT", 0, false}};
+// Development overrides (ssd_dev_knob): A/B timing of kernel variants and forcing a dispatch path in tests, inside one
+// process.  NOT configuration: the product never sets them, nothing is read from the environment, and results never
+// depend on them (every variant computes the same convolution).  Values are relaxed atomics (-1 in the table = unset:
+// the caller's default applies), so concurrent calls are safe.
+struct Knob { const char* name; std::atomic<int> value; };
+constexpr int KNOB_UNSET = INT_MIN;
+Knob g_knobs[] = {{"SSD_ABLATE", {KNOB_UNSET}}, {"SSD_DGRAD_S2", {KNOB_UNSET}}, {"SSD_CONV_VARIANT", {KNOB_UNSET}},
+                  {"SSD_CONV_PATCH", {KNOB_UNSET}}, {"SSD_CONV_TILE", {KNOB_UNSET}}, {"SSD_SPLITK", {KNOB_UNSET}},
+                  {"SSD_WGRAD_DMA", {KNOB_UNSET}}, {"SSD_WGRAD_PATCH", {KNOB_UNSET}}, {"SSD_WGRAD_PATCH_SINGLE", {KNOB_UNSET}},
+                  {"SSD_WGRAD_PATCH_SHAPE", {KNOB_UNSET}}, {"SSD_WGRAD_TILE", {KNOB_UNSET}}, {"SSD_CONV_PATCH_FORM", {KNOB_UNSET}},
+                  {"SSD_CONV_PATCH_FLAT", {KNOB_UNSET}}, {"SSD_WGRAD_FIRST", {KNOB_UNSET}}, {"SSD_CONV_FIRST", {KNOB_UNSET}},
+                  {"SSD_WGRAD_PATCH_XCD", {KNOB_UNSET}}, {"SSD_CONV_C64", {KNOB_UNSET}}, {"SSD_CONV_POOL_FUSE", {KNOB_UNSET}},
+                  {"SSD_CONV_PATCH_ROWFLAT", {KNOB_UNSET}}, {"SSD_CONV_PW", {KNOB_UNSET}}};
 Knob* find_knob(const char* name) {
     for (Knob& k : g_knobs) if (!strcmp(k.name, name)) return &k;
     return nullptr;
@@ -3030,8 +3040,21 @@ Knob* find_knob(const char* name) {
 int knob(const char* name, int dflt) {
     Knob* k = find_knob(name);
     if (!k) return dflt;
-    if (!k->init) { const char* e = getenv(name); k->value = e ? atoi(e) : dflt; k->init = true; }
-    return k->value;
+    const int v = k->value.load(std::memory_order_relaxed);
+    return v == KNOB_UNSET ? dflt : v;
+}
+
+// Kernels that need more than 64 KB of dynamic LDS are registered once per device (idempotent; a racing second thread
+// repeats the same call).  No other process-wide state exists in this library.
+struct OnceLds { std::atomic<unsigned> done{0}; };
+int ensure_lds(OnceLds& o, const void* fn, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    const unsigned bit = 1u << (dev & 31);
+    if (o.done.load(std::memory_order_acquire) & bit) return 0;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return -1;
+    o.done.fetch_or(bit, std::memory_order_release);
+    return 0;
 }
 
 ConvGeom make_geom(int B, int H, int W, int C, int Ho, int Wo, int N, int KH, int KW, int mul, int div, int pad_t,
@@ -3057,13 +3080,17 @@ ConvGeom make_geom(int B, int H, int W, int C, int Ho, int Wo, int N, int KH, in
     return g;
 }
 
+// Which kernel a call resolves to (ssd_conv2d_*_plan): the dispatch code below runs as usual and, with `plan` set, records
+// the id at the launch site and returns instead of launching -- the query cannot drift from the dispatch.
+#define SSD_PLAN(ID_) do { if (plan) { *plan = (ID_); return SSD_OK; } } while (0)
+
 int igemm_variant() {                       // SSD_CONV_VARIANT=0: register-staged kernel, 1: LDS-DMA kernels, 2 (default): + 8-phase 256x256
     return knob("SSD_CONV_VARIANT", 2);
 }
 
 template <int EPI>
 int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue& ep_in, hipStream_t s, void* ws = nullptr,
-                 size_t ws_bytes = 0, bool* pooled = nullptr) {
+                 size_t ws_bytes = 0, bool* pooled = nullptr, int* plan = nullptr) {
     const bf16_raw* xp = static_cast<const bf16_raw*>(x);
     const bf16_raw* wp = static_cast<const bf16_raw*>(w);
     Epilogue ep = ep_in;
@@ -3079,8 +3106,8 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
                 const int tiles_x = (g.Wo + 15) / 16, tiles_y = (g.Ho + C64B_ROWS - 1) / C64B_ROWS;
                 const int nblocks = g.B * tiles_x * tiles_y;
                 auto kern = k_conv3x3_c64b<EPI>;
-                static bool set = false;
-                if (!set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C64B_LDS) != hipSuccess) return SSD_ERR_LAUNCH; set = true; }
+                SSD_PLAN(SSD_PLAN_C64B | ((pooled && ep.pool_out) ? SSD_PLAN_F_POOL_FUSED : 0));
+                static OnceLds set; if (ensure_lds(set, reinterpret_cast<const void*>(kern), (int)(C64B_LDS)) != 0) return SSD_ERR_LAUNCH;
                 hipLaunchKernelGGL(kern, dim3((unsigned)(nblocks < 512 ? nblocks : 512)), dim3(256), C64B_LDS, s, xp, wp, g, ep, tiles_x, tiles_y);
                 if (pooled && ep.pool_out) *pooled = true;
                 return ssd_launch_status();
@@ -3089,8 +3116,8 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
             const int nblocks = g.B * tiles_x * tiles_y;
             constexpr int lds = 2 * C64_PATCH + 32768;
             auto kern = k_conv3x3_c64<EPI>;
-            static bool set = false;
-            if (!set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return SSD_ERR_LAUNCH; set = true; }
+            SSD_PLAN(SSD_PLAN_C64 | ((pooled && ep.pool_out) ? SSD_PLAN_F_POOL_FUSED : 0));
+            static OnceLds set; if (ensure_lds(set, reinterpret_cast<const void*>(kern), (int)(lds)) != 0) return SSD_ERR_LAUNCH;
             hipLaunchKernelGGL(kern, dim3((unsigned)(nblocks < 256 ? nblocks : 256)), dim3(512), lds, s, xp, wp, g, ep, tiles_x, tiles_y);
             if (pooled && ep.pool_out) *pooled = true;
             return ssd_launch_status();
@@ -3121,12 +3148,9 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
             do {                                                                                                    \
                 constexpr int lds_ = 2 * P32_PATCH + 2 * BN_ * 64 + (BN_ == 64 ? 1024 : 0);                         \
                 auto kern_ = k_conv3x3_patch32<BN_, EPI, FLAT_>;                                                    \
-                static bool set_ = false;                                                                           \
-                if (!set_) {                                                                                        \
-                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, lds_) != hipSuccess) \
-                        return SSD_ERR_LAUNCH;                                                                      \
-                    set_ = true;                                                                                    \
-                }                                                                                                   \
+                SSD_PLAN((BN_ == 64 ? SSD_PLAN_P32_64 : SSD_PLAN_P32_128) | (FLAT_ ? SSD_PLAN_F_FLAT : 0) |            \
+                         (rowflat ? SSD_PLAN_F_ROWFLAT : 0) | (can_pool ? SSD_PLAN_F_POOL_FUSED : 0));                \
+                static OnceLds set_; if (ensure_lds(set_, reinterpret_cast<const void*>(kern_), (int)(lds_)) != 0) return SSD_ERR_LAUNCH; \
                 const unsigned ntn_ = (unsigned)((g.N + BN_ - 1) / BN_);                                            \
                 hipLaunchKernelGGL(kern_, dim3(8 * ntn_ * ((gxx + 7) / 8)), dim3(512), lds_, s, xp, wp, g, ep, tiles_x, tiles_y, (int)gxx, rowflat); \
             } while (0)
@@ -3142,14 +3166,14 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
         if (g.N <= 64) {
             const size_t lds = 2 * 64 * 128 + PATCH_BYTES;
             auto kern = k_conv3x3_patch<64, EPI>;
-            static bool set = false;
-            if (!set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 128 + PATCH_BYTES) != hipSuccess) return SSD_ERR_LAUNCH; set = true; }
+            SSD_PLAN(SSD_PLAN_PATCH_64);
+            static OnceLds set; if (ensure_lds(set, reinterpret_cast<const void*>(kern), (int)(2 * 64 * 128 + PATCH_BYTES)) != 0) return SSD_ERR_LAUNCH;
             hipLaunchKernelGGL(kern, dim3(gx, (unsigned)((g.N + 63) / 64)), dim3(512), lds, s, xp, wp, g, ep, tiles_x, tiles_y);
         } else {
             const size_t lds = 2 * 128 * 128 + PATCH_BYTES;
             auto kern = k_conv3x3_patch<128, EPI>;
-            static bool set = false;
-            if (!set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 128 + PATCH_BYTES) != hipSuccess) return SSD_ERR_LAUNCH; set = true; }
+            SSD_PLAN(SSD_PLAN_PATCH_128);
+            static OnceLds set; if (ensure_lds(set, reinterpret_cast<const void*>(kern), (int)(2 * 128 * 128 + PATCH_BYTES)) != 0) return SSD_ERR_LAUNCH;
             hipLaunchKernelGGL(kern, dim3(gx, (unsigned)((g.N + 127) / 128)), dim3(512), lds, s, xp, wp, g, ep, tiles_x, tiles_y);
         }
         return ssd_launch_status();
@@ -3193,14 +3217,11 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
             constexpr int NT_ = (BM_ / (16 * PT_)) * (BN_ >= 128 ? BN_ / 64 : 2) * 64;                              \
             const size_t lds_ = 2 * (BM_ + BN_) * 128;                                                             \
             auto kern_ = k_conv_igemm_dma<BM_, BN_, EPI, PT_>;                                                     \
+            SSD_PLAN((BM_ == 256 ? (BN_ == 256 ? SSD_PLAN_DMA_256_256 : (BN_ == 128 ? SSD_PLAN_DMA_256_128 : SSD_PLAN_DMA_256_64)) \
+                                 : (BN_ == 64 ? SSD_PLAN_DMA_128_64 : SSD_PLAN_DMA_128_128)) |                       \
+                     (ksplit > 1 ? SSD_PLAN_F_SPLITK : 0) | (g.s2 ? SSD_PLAN_F_S2 : 0));                              \
             if (lds_ > 65536) {                                                                                    \
-                static bool set_ = false;                                                                          \
-                if (!set_) {                                                                                       \
-                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern_),                                   \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_) != hipSuccess)   \
-                        return SSD_ERR_LAUNCH;                                                                     \
-                    set_ = true;                                                                                   \
-                }                                                                                                  \
+                static OnceLds set_; if (ensure_lds(set_, reinterpret_cast<const void*>(kern_), (int)((int)lds_)) != 0) return SSD_ERR_LAUNCH; \
             }                                                                                                      \
             unsigned ntm_ = (unsigned)((g.M + BM_ - 1) / BM_);                                                      \
             const unsigned ntn_ = (unsigned)((g.N + BN_ - 1) / BN_);                                               \
@@ -3213,12 +3234,8 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
 #define SSD_LAUNCH_8PH(ABL_)                                                                                        \
             do {                                                                                                    \
                 auto kern = k_conv_igemm_8ph<EPI, ABL_>;                                                            \
-                static bool set = false;                                                                            \
-                if (!set) {                                                                                         \
-                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 131072) != hipSuccess) \
-                        return SSD_ERR_LAUNCH;                                                                      \
-                    set = true;                                                                                     \
-                }                                                                                                   \
+                SSD_PLAN(SSD_PLAN_8PH);                                                                             \
+                static OnceLds set; if (ensure_lds(set, reinterpret_cast<const void*>(kern), (int)(131072)) != 0) return SSD_ERR_LAUNCH; \
                 hipLaunchKernelGGL(kern, dim3(8 * ntn * ((ntm + 7) / 8)), dim3(512), 131072, s, xp, wp, g, ep);      \
             } while (0)
 #ifdef SSD_DEV_ABLATE
@@ -3250,6 +3267,7 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
         }
         return ssd_launch_status();
     }
+    SSD_PLAN(g.N <= 64 ? SSD_PLAN_REG_64 : SSD_PLAN_REG_128);
     if (g.N <= 64) {
         const size_t lds = 2 * (128 + 64) * 128;
         hipLaunchKernelGGL((k_conv_igemm<64, EPI>), dim3(gm, (unsigned)((g.N + 63) / 64)), dim3(WG), lds, s, xp, wp, g, ep);
@@ -3276,18 +3294,18 @@ int ssd_dev_knob(const char* name, int value) {
     if (!name) return SSD_ERR_VALUE;
     Knob* k = find_knob(name);
     if (!k) return SSD_ERR_VALUE;
-    k->value = value;
-    k->init = true;
+    k->value.store(value, std::memory_order_relaxed);
     return SSD_OK;
 }
 
-int ssd_conv2d_fwd(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
-                   int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int relu, void* ws, size_t ws_bytes,
-                   void* stream) {
+static int conv2d_fwd_impl(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
+                           int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int relu, void* ws, size_t ws_bytes,
+                           void* stream, int* plan) {
     if (!x || !w || !y || !geom_ok(B, H, W, Cin, Ho, Wo, Cout, ksize) || stride <= 0) return SSD_ERR_VALUE;
     const ConvGeom g = make_geom(B, H, W, Cin, Ho, Wo, Cout, ksize, ksize, stride, 1, pad_t, pad_l);
     if (knob("SSD_CONV_FIRST", 1) && Cin == 8 && Cout == 64 && ksize == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && H == Ho &&
         W == Wo && H >= 16 && W >= 16) {                     // the image layer
+        SSD_PLAN(SSD_PLAN_CONV0_FWD);
         const int tx = (Wo + 15) / 16, ty = (Ho + 15) / 16;
         hipLaunchKernelGGL(k_conv0_fwd, dim3((unsigned)(B * tx * ty < 768 ? B * tx * ty : 768)), dim3(512), 0, (hipStream_t)stream,
                            static_cast<const bf16_raw*>(x), static_cast<const bf16_raw*>(w), bias, static_cast<bf16_raw*>(y), g, relu,
@@ -3296,12 +3314,19 @@ int ssd_conv2d_fwd(const void* x, const void* w, const float* bias, void* y, int
     }
     Epilogue ep = {};
     ep.bias = bias; ep.relu = relu; ep.out = static_cast<bf16_raw*>(y); ep.ldo = Cout;
-    return launch_igemm<EPI_FWD>(x, w, g, ep, (hipStream_t)stream, ws, ws_bytes);
+    return launch_igemm<EPI_FWD>(x, w, g, ep, (hipStream_t)stream, ws, ws_bytes, nullptr, plan);
 }
 
-int ssd_conv2d_fwd_pool(const void* x, const void* w, const float* bias, void* y, void* y_pool, void* pool_code, int B, int H,
-                        int W, int Cin, int Cout, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int relu, int Hp,
-                        int Wp, void* ws, size_t ws_bytes, void* stream) {
+int ssd_conv2d_fwd(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
+                   int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int relu, void* ws, size_t ws_bytes,
+                   void* stream) {
+    return conv2d_fwd_impl(x, w, bias, y, B, H, W, Cin, Cout, ksize, stride, pad_t, pad_l, Ho, Wo, relu, ws, ws_bytes, stream,
+                           nullptr);
+}
+
+static int conv2d_fwd_pool_impl(const void* x, const void* w, const float* bias, void* y, void* y_pool, void* pool_code, int B,
+                                int H, int W, int Cin, int Cout, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo,
+                                int relu, int Hp, int Wp, void* ws, size_t ws_bytes, void* stream, int* plan) {
     if (!x || !w || !y_pool || !pool_code || !geom_ok(B, H, W, Cin, Ho, Wo, Cout, ksize) || stride <= 0 || Cout % 8)
         return SSD_ERR_VALUE;
     // y == NULL: the caller has no use for the full-resolution map (nothing but the pooling reads it): served only by the
@@ -3315,15 +3340,22 @@ int ssd_conv2d_fwd_pool(const void* x, const void* w, const float* bias, void* y
         ep.pool_out = static_cast<bf16_raw*>(y_pool); ep.pool_code = static_cast<unsigned*>(pool_code); ep.pool_h = Hp; ep.pool_w = Wp;
     }
     bool pooled = false;
-    const int rc = launch_igemm<EPI_FWD>(x, w, g, ep, (hipStream_t)stream, ws, ws_bytes, &pooled);
-    if (rc != SSD_OK || pooled) return rc;
+    const int rc = launch_igemm<EPI_FWD>(x, w, g, ep, (hipStream_t)stream, ws, ws_bytes, &pooled, plan);
+    if (rc != SSD_OK || pooled || plan) return rc;
     // this layer is not served by a 16x16-block kernel: pool in a second launch
     return ssd_maxpool2x2_fwd_argmax(y, y_pool, pool_code, B, Ho, Wo, Cout, Hp, Wp, stream);
 }
 
-int ssd_conv2d_head_fwd(const void* x, const void* w, const float* bias, void* loc, void* conf, int B, int H, int W,
-                        int Cin, int per_cell, int classes, int anchors_total, int level_off, void* ws, size_t ws_bytes,
-                        void* stream) {
+int ssd_conv2d_fwd_pool(const void* x, const void* w, const float* bias, void* y, void* y_pool, void* pool_code, int B, int H,
+                        int W, int Cin, int Cout, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int relu, int Hp,
+                        int Wp, void* ws, size_t ws_bytes, void* stream) {
+    return conv2d_fwd_pool_impl(x, w, bias, y, y_pool, pool_code, B, H, W, Cin, Cout, ksize, stride, pad_t, pad_l, Ho, Wo, relu,
+                                Hp, Wp, ws, ws_bytes, stream, nullptr);
+}
+
+static int conv2d_head_fwd_impl(const void* x, const void* w, const float* bias, void* loc, void* conf, int B, int H, int W,
+                                int Cin, int per_cell, int classes, int anchors_total, int level_off, void* ws, size_t ws_bytes,
+                                void* stream, int* plan) {
     const int N = per_cell * (4 + classes);
     if (!x || !w || !loc || !conf || !geom_ok(B, H, W, Cin, H, W, N, 3) || per_cell <= 0 || classes <= 0) return SSD_ERR_VALUE;
     const ConvGeom g = make_geom(B, H, W, Cin, H, W, N, 3, 3, 1, 1, 1, 1);   // 3x3 SAME stride 1 (models/ssd_model.py:155-162)
@@ -3331,12 +3363,19 @@ int ssd_conv2d_head_fwd(const void* x, const void* w, const float* bias, void* l
     ep.bias = bias; ep.loc = static_cast<bf16_raw*>(loc); ep.conf = static_cast<bf16_raw*>(conf);
     ep.n_loc = per_cell * 4; ep.n_conf = per_cell * classes; ep.anchors_total = anchors_total;
     ep.level_off = level_off; ep.per_cell = per_cell; ep.classes = classes;
-    return launch_igemm<EPI_HEAD>(x, w, g, ep, (hipStream_t)stream, ws, ws_bytes);
+    return launch_igemm<EPI_HEAD>(x, w, g, ep, (hipStream_t)stream, ws, ws_bytes, nullptr, plan);
 }
 
-int ssd_conv2d_bwd_data(const void* dy, const void* w_t, const void* relu_src, void* dx, int B, int H, int W, int Cin,
-                        int Cout_pad, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int accumulate,
-                        void* ws, size_t ws_bytes, void* stream) {
+int ssd_conv2d_head_fwd(const void* x, const void* w, const float* bias, void* loc, void* conf, int B, int H, int W,
+                        int Cin, int per_cell, int classes, int anchors_total, int level_off, void* ws, size_t ws_bytes,
+                        void* stream) {
+    return conv2d_head_fwd_impl(x, w, bias, loc, conf, B, H, W, Cin, per_cell, classes, anchors_total, level_off, ws, ws_bytes,
+                                stream, nullptr);
+}
+
+static int conv2d_bwd_data_impl(const void* dy, const void* w_t, const void* relu_src, void* dx, int B, int H, int W, int Cin,
+                                int Cout_pad, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int accumulate,
+                                void* ws, size_t ws_bytes, void* stream, int* plan) {
     // dy: [B,Ho,Wo,Cout_pad]; w_t: [Cin][k][k][Cout_pad] (ssd_weight_transpose); dx, relu_src: [B,H,W,Cin]
     if (!dy || !w_t || !dx || !geom_ok(B, Ho, Wo, Cout_pad, H, W, Cin, ksize) || stride <= 0) return SSD_ERR_VALUE;
     const ConvGeom g = make_geom(B, Ho, Wo, Cout_pad, H, W, Cin, ksize, ksize, 1, stride, ksize - 1 - pad_t,
@@ -3344,7 +3383,14 @@ int ssd_conv2d_bwd_data(const void* dy, const void* w_t, const void* relu_src, v
     Epilogue ep = {};
     ep.out = static_cast<bf16_raw*>(dx); ep.ldo = Cin; ep.mask_src = static_cast<const bf16_raw*>(relu_src);
     ep.accumulate = accumulate;
-    return launch_igemm<EPI_DGRAD>(dy, w_t, g, ep, (hipStream_t)stream, ws, ws_bytes);
+    return launch_igemm<EPI_DGRAD>(dy, w_t, g, ep, (hipStream_t)stream, ws, ws_bytes, nullptr, plan);
+}
+
+int ssd_conv2d_bwd_data(const void* dy, const void* w_t, const void* relu_src, void* dx, int B, int H, int W, int Cin,
+                        int Cout_pad, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int accumulate,
+                        void* ws, size_t ws_bytes, void* stream) {
+    return conv2d_bwd_data_impl(dy, w_t, relu_src, dx, B, H, W, Cin, Cout_pad, ksize, stride, pad_t, pad_l, Ho, Wo, accumulate,
+                                ws, ws_bytes, stream, nullptr);
 }
 
 static int wgrad_dma() {                    // SSD_WGRAD_DMA=1: LDS-DMA weight-gradient kernel (default: register-staged)
@@ -3471,9 +3517,9 @@ size_t ssd_conv2d_bwd_weight_workspace_bytes(int B, int Ho, int Wo, int Cin, int
     return gen > patch_bytes ? gen : patch_bytes;
 }
 
-int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias, int B, int H, int W, int Cin, int Cout,
-                          int ldy, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, void* ws, size_t ws_bytes,
-                          void* stream) {
+static int conv2d_bwd_weight_impl(const void* x, const void* dy, float* dw, float* dbias, int B, int H, int W, int Cin, int Cout,
+                                  int ldy, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, void* ws, size_t ws_bytes,
+                                  void* stream, int* plan) {
     // x: [B,H,W,Cin]; dy: [B,Ho,Wo,ldy] (first Cout channels used); dw: f32 [Cout][k][k][Cin]; dbias: f32 [Cout] or null
     if (!x || !dy || !dw || !geom_ok(B, H, W, Cin, Ho, Wo, Cout, ksize) || stride <= 0 || ldy < Cout || ldy % 8) return SSD_ERR_VALUE;
     if (!ws || ws_bytes < ssd_conv2d_bwd_weight_workspace_bytes(B, Ho, Wo, Cin, Cout, ldy, ksize)) return SSD_ERR_WORKSPACE;
@@ -3483,15 +3529,11 @@ int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias
         const int tx = (Wo + 15) / 16, ty = (Ho + 15) / 16, ntiles = B * tx * ty;
         const int ns = ntiles < 512 ? ntiles : 512;
         const int tps = (ntiles + ns - 1) / ns;
+        SSD_PLAN(SSD_PLAN_WG_FIRST | ((ntiles + tps - 1) / tps >= 32 ? SSD_PLAN_F_REDUCE_WIDE : 0));
         float* slab_w = static_cast<float*>(ws);
         float* slab_b = slab_w + (size_t)ns * ldy * ktot;
         hipStream_t s = (hipStream_t)stream;
-        static bool set = false;
-        if (!set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv0_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    2 * W0_BUF) != hipSuccess) return SSD_ERR_LAUNCH;
-            set = true;
-        }
+        static OnceLds set; if (ensure_lds(set, reinterpret_cast<const void*>(k_conv0_wgrad), (int)(2 * W0_BUF)) != 0) return SSD_ERR_LAUNCH;
         hipLaunchKernelGGL(k_conv0_wgrad, dim3((unsigned)((ntiles + tps - 1) / tps)), dim3(512), 2 * W0_BUF, s,
                            static_cast<const bf16_raw*>(x), static_cast<const bf16_raw*>(dy), slab_w, dbias ? slab_b : nullptr, g,
                            tx, ty, tps, Cout);
@@ -3521,16 +3563,13 @@ int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias
         const unsigned grid = (unsigned)(8 * xg * ((nunits + 8 * xg - 1) / (8 * xg)));
         int bh, bw;
         const int shape = wgrad_patch_shape(Ho, Wo, &bh, &bw);
+        SSD_PLAN((shape == 1 ? SSD_PLAN_WG_PATCH_6x40 : (shape == 2 ? SSD_PLAN_WG_PATCH_10x24 : SSD_PLAN_WG_PATCH_16x16)) |
+                 (ns >= 32 ? SSD_PLAN_F_REDUCE_WIDE : 0));
 #define SSD_LAUNCH_WP(BH_, BW8_)                                                                                    \
         do {                                                                                                        \
             using G_ = WpGeom<BH_, BW8_>;                                                                           \
             auto kern_ = k_conv3x3_wgrad_patch<BH_, BW8_>;                                                          \
-            static bool set_ = false;                                                                               \
-            if (!set_) {                                                                                            \
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                        2 * G_::BUF) != hipSuccess) return SSD_ERR_LAUNCH;                           \
-                set_ = true;                                                                                        \
-            }                                                                                                       \
+            static OnceLds set_; if (ensure_lds(set_, reinterpret_cast<const void*>(kern_), (int)(2 * G_::BUF)) != 0) return SSD_ERR_LAUNCH; \
             hipLaunchKernelGGL(kern_, dim3(grid), dim3(512), (size_t)(single ? 1 : 2) * G_::BUF, s,                  \
                                static_cast<const bf16_raw*>(x), static_cast<const bf16_raw*>(dy), slab_w,          \
                                dbias ? slab_b : nullptr, g, tx, ty, tps, ns, Cout, single, xg);                     \
@@ -3548,15 +3587,11 @@ int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias
         const int ns = wgrad_tile_splits(g.M, ctiles * mtiles, (long long)ldy * ktot);
         int mps = (int)(((long long)g.M + ns - 1) / ns);
         mps = (mps + 63) / 64 * 64;
+        SSD_PLAN(SSD_PLAN_WG_TILE | (ns >= 32 ? SSD_PLAN_F_REDUCE_WIDE : 0));
         float* slab_w = static_cast<float*>(ws);
         float* slab_b = slab_w + (size_t)ns * ldy * ktot;
         hipStream_t s = (hipStream_t)stream;
-        static bool set = false;
-        if (!set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad_tile), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    4 * WT_TILE) != hipSuccess) return SSD_ERR_LAUNCH;
-            set = true;
-        }
+        static OnceLds set; if (ensure_lds(set, reinterpret_cast<const void*>(k_conv_wgrad_tile), (int)(4 * WT_TILE)) != 0) return SSD_ERR_LAUNCH;
         hipLaunchKernelGGL(k_conv_wgrad_tile, dim3(ctiles * mtiles * ns), dim3(512), 4 * WT_TILE, s,
                            static_cast<const bf16_raw*>(x), static_cast<const bf16_raw*>(dy), slab_w, dbias ? slab_b : nullptr, g,
                            mps, ns, Cout);
@@ -3570,6 +3605,7 @@ int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias
     const int ns = wgrad_splits(g.M, ctiles * mtiles);
     int mps = (int)(((long long)g.M + ns - 1) / ns);
     mps = (mps + 63) / 64 * 64;
+    SSD_PLAN((wgrad_dma() ? SSD_PLAN_WG_DMA : SSD_PLAN_WG_GENERIC) | (ns >= 32 ? SSD_PLAN_F_REDUCE_WIDE : 0));
     float* slab_w = static_cast<float*>(ws);
     float* slab_b = slab_w + (size_t)ns * ldy * ktot;
     hipStream_t s = (hipStream_t)stream;
@@ -3578,12 +3614,7 @@ int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias
     float* sb = dbias ? slab_b : nullptr;
     if (!wgrad_dma()) {
         const size_t lds = 4 * 64 * WG_LD;
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds) != hipSuccess) return SSD_ERR_LAUNCH;
-            attr_set = true;
-        }
+        static OnceLds attr_set; if (ensure_lds(attr_set, reinterpret_cast<const void*>(k_conv_wgrad), (int)((int)lds)) != 0) return SSD_ERR_LAUNCH;
         hipLaunchKernelGGL(k_conv_wgrad, dim3(ctiles, mtiles, ns), dim3(WG), lds, s, xp, dyp, slab_w, sb, g, mps);
     } else {
 #define SSD_LAUNCH_WG(BMO_, BNC_)                                                                                  \
@@ -3593,13 +3624,7 @@ int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias
             const size_t lds_ = 2 * 64 * (BMO_ + BNC_) * 2;                                                        \
             auto kern_ = k_conv_wgrad_dma<BMO_, BNC_, AT_>;                                                        \
             if (lds_ > 65536) {                                                                                    \
-                static bool set_ = false;                                                                          \
-                if (!set_) {                                                                                       \
-                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern_),                                   \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_) != hipSuccess)   \
-                        return SSD_ERR_LAUNCH;                                                                     \
-                    set_ = true;                                                                                   \
-                }                                                                                                  \
+                static OnceLds set_; if (ensure_lds(set_, reinterpret_cast<const void*>(kern_), (int)((int)lds_)) != 0) return SSD_ERR_LAUNCH; \
             }                                                                                                      \
             hipLaunchKernelGGL(kern_, dim3(8 * ctiles * mtiles * ((ns + 7) / 8)), dim3(NT_), lds_, s, xp, dyp, slab_w, \
                                sb, g, mps, ns, Cout);                                                              \
@@ -3615,6 +3640,85 @@ int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias
     if (hipGetLastError() != hipSuccess) return SSD_ERR_LAUNCH;
     launch_wgrad_reduce(s, slab_w, (long long)ldy * ktot, (long long)Cout * ktot, dw, slab_b, (long long)ldy, Cout, dbias, ns);
     return ssd_launch_status();
+}
+
+int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias, int B, int H, int W, int Cin, int Cout,
+                          int ldy, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, void* ws, size_t ws_bytes,
+                          void* stream) {
+    return conv2d_bwd_weight_impl(x, dy, dw, dbias, B, H, W, Cin, Cout, ldy, ksize, stride, pad_t, pad_l, Ho, Wo, ws, ws_bytes,
+                                  stream, nullptr);
+}
+
+// ---- dispatch queries: the same code path with `plan` set (nothing is launched, no pointer is dereferenced) ----
+static void* const PLAN_PTR = reinterpret_cast<void*>(static_cast<uintptr_t>(64));
+
+int ssd_conv2d_fwd_plan(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo,
+                        int pool, size_t ws_bytes) {
+    int plan = 0, rc;
+    void* ws = ws_bytes ? PLAN_PTR : nullptr;
+    if (pool) {
+        const int Hp = (Ho + 1) / 2, Wp = (Wo + 1) / 2;
+        rc = conv2d_fwd_pool_impl(PLAN_PTR, PLAN_PTR, nullptr, pool == 2 ? nullptr : PLAN_PTR, PLAN_PTR, PLAN_PTR, B, H, W, Cin, Cout,
+                                  ksize, stride, pad_t, pad_l, Ho, Wo, 1, Hp, Wp, ws, ws_bytes, nullptr, &plan);
+    } else {
+        rc = conv2d_fwd_impl(PLAN_PTR, PLAN_PTR, nullptr, PLAN_PTR, B, H, W, Cin, Cout, ksize, stride, pad_t, pad_l, Ho, Wo, 1, ws,
+                             ws_bytes, nullptr, &plan);
+    }
+    return rc != SSD_OK ? rc : plan;
+}
+
+int ssd_conv2d_head_fwd_plan(int B, int H, int W, int Cin, int per_cell, int classes, size_t ws_bytes) {
+    int plan = 0;
+    const int rc = conv2d_head_fwd_impl(PLAN_PTR, PLAN_PTR, nullptr, PLAN_PTR, PLAN_PTR, B, H, W, Cin, per_cell, classes,
+                                        H * W * per_cell, 0, ws_bytes ? PLAN_PTR : nullptr, ws_bytes, nullptr, &plan);
+    return rc != SSD_OK ? rc : plan;
+}
+
+int ssd_conv2d_bwd_data_plan(int B, int H, int W, int Cin, int Cout_pad, int ksize, int stride, int pad_t, int pad_l, int Ho,
+                             int Wo, int accumulate, size_t ws_bytes) {
+    int plan = 0;
+    const int rc = conv2d_bwd_data_impl(PLAN_PTR, PLAN_PTR, nullptr, PLAN_PTR, B, H, W, Cin, Cout_pad, ksize, stride, pad_t, pad_l,
+                                        Ho, Wo, accumulate, ws_bytes ? PLAN_PTR : nullptr, ws_bytes, nullptr, &plan);
+    return rc != SSD_OK ? rc : plan;
+}
+
+int ssd_conv2d_bwd_weight_plan(int B, int H, int W, int Cin, int Cout, int ldy, int ksize, int stride, int pad_t, int pad_l,
+                               int Ho, int Wo) {
+    int plan = 0;
+    const size_t need = ssd_conv2d_bwd_weight_workspace_bytes(B, Ho, Wo, Cin, Cout, ldy, ksize);
+    const int rc = conv2d_bwd_weight_impl(PLAN_PTR, PLAN_PTR, reinterpret_cast<float*>(PLAN_PTR), reinterpret_cast<float*>(PLAN_PTR),
+                                          B, H, W, Cin, Cout, ldy, ksize, stride, pad_t, pad_l, Ho, Wo, PLAN_PTR, need, nullptr,
+                                          &plan);
+    return rc != SSD_OK ? rc : plan;
+}
+
+const char* ssd_conv_plan_name(int plan) {
+    switch (plan & SSD_PLAN_KERNEL_MASK) {
+        case SSD_PLAN_C64B: return "k_conv3x3_c64b";
+        case SSD_PLAN_C64: return "k_conv3x3_c64";
+        case SSD_PLAN_P32_64: return "k_conv3x3_patch32<64>";
+        case SSD_PLAN_P32_128: return "k_conv3x3_patch32<128>";
+        case SSD_PLAN_PATCH_64: return "k_conv3x3_patch<64>";
+        case SSD_PLAN_PATCH_128: return "k_conv3x3_patch<128>";
+        case SSD_PLAN_8PH: return "k_conv_igemm_8ph";
+        case SSD_PLAN_DMA_256_256: return "k_conv_igemm_dma<256,256>";
+        case SSD_PLAN_DMA_256_128: return "k_conv_igemm_dma<256,128>";
+        case SSD_PLAN_DMA_256_64: return "k_conv_igemm_dma<256,64>";
+        case SSD_PLAN_DMA_128_64: return "k_conv_igemm_dma<128,64>";
+        case SSD_PLAN_DMA_128_128: return "k_conv_igemm_dma<128,128>";
+        case SSD_PLAN_REG_64: return "k_conv_igemm<64>";
+        case SSD_PLAN_REG_128: return "k_conv_igemm<128>";
+        case SSD_PLAN_CONV0_FWD: return "k_conv0_fwd";
+        case SSD_PLAN_PW: return "k_conv_pw";
+        case SSD_PLAN_WG_FIRST: return "k_conv0_wgrad";
+        case SSD_PLAN_WG_PATCH_16x16: return "k_conv3x3_wgrad_patch<16,2>";
+        case SSD_PLAN_WG_PATCH_6x40: return "k_conv3x3_wgrad_patch<6,5>";
+        case SSD_PLAN_WG_PATCH_10x24: return "k_conv3x3_wgrad_patch<10,3>";
+        case SSD_PLAN_WG_TILE: return "k_conv_wgrad_tile";
+        case SSD_PLAN_WG_GENERIC: return "k_conv_wgrad";
+        case SSD_PLAN_WG_DMA: return "k_conv_wgrad_dma";
+        default: return "?";
+    }
 }
 
 int ssd_weight_transpose(const void* w, void* w_t, int Cout, int ksize, int Cin, int Cout_pad, void* stream) {

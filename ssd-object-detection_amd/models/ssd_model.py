@@ -368,11 +368,12 @@ class SSDObjectDetectionModel:
         keep = ops.nms(score, cls, box, cand, iou_thresh, max_cand)
         return score, cls, box, keep
 
-    def evaluate(self, samples, batch_size=32, score_thresh=0.05, iou_thresh=0.45, max_dets=100):
+    def evaluate(self, samples, batch_size=32, score_thresh=0.05, iou_thresh=0.45, max_dets=100, return_detections=False):
         """Evaluation pass (the reference fetches its val split at models/ssd_model.py:291 and drops it):
         samples = iterable of (image f32 [S,S,3] in [0,1], cls [n], box [n,4] relative cx,cy,w,h) as the loaders yield
         them.  Network forward, scoring/decoding and per-class NMS run on the device; the kept detections go to
-        utils.metrics.coco_map on the host.  Returns its dict (mAP = AP@[.5:.95], AP50, AP75, per_class)."""
+        utils.metrics.coco_map on the host.  Returns its dict (mAP = AP@[.5:.95], AP50, AP75, per_class); with
+        return_detections also the per-image (score, cls, box_px) arrays that were scored."""
         from ..utils.metrics import coco_map
         size = float(self.cfg.input_shape[0])
         dets, gts, buf = [], [], []
@@ -394,7 +395,8 @@ class SSDObjectDetectionModel:
             if len(buf) == batch_size:
                 flush()
         flush()
-        return coco_map(dets, gts, max_dets=max_dets)
+        result = coco_map(dets, gts, max_dets=max_dets)
+        return (result, dets) if return_detections else result
 
     # ------------------------------------------------------------------ checkpoint
     def save(self, path="model_weight.pt", extra=None, collective=True):

@@ -29,31 +29,7 @@ def ref_conv(x, w, bias, k, stride, pad_t, pad_l, Ho, Wo, relu):
     return y.permute(0, 2, 3, 1).contiguous()
 
 
-CASES = [
-    # B, H, W, Cin, Cout, k, stride, mode
-    (2, 38, 38, 64, 128, 3, 1, "same"),      # 3x3 SAME, BN=128 path
-    (2, 30, 30, 64, 64, 3, 1, "same"),       # BN=64 path
-    (3, 19, 19, 128, 256, 1, 1, "same"),     # 1x1
-    (2, 38, 38, 64, 96, 3, 2, "same"),       # stride 2, pad (0,1)  (38 -> 19)
-    (2, 19, 19, 64, 72, 3, 2, "same"),       # stride 2, pad (1,1)  (19 -> 10), N not a multiple of 16
-    (4, 5, 5, 128, 256, 3, 1, "valid"),      # 3x3 VALID (5 -> 3)
-    (5, 3, 3, 128, 256, 3, 1, "valid"),      # 3 -> 1, M = 5
-    (2, 20, 20, 8, 64, 3, 1, "same"),        # Cin = 8 (the padded image layer): taps share a k-step
-    (2, 40, 40, 128, 64, 3, 1, "same"),      # LDS-patch kernel, two channel chunks, BN = 64, partial edge tiles
-    (1, 50, 35, 128, 128, 3, 1, "same"),     # LDS-patch kernel, BN = 128, non-square, both dims partial
-    (2, 33, 33, 192, 96, 3, 1, "same"),      # LDS-patch kernel, three chunks, N not a multiple of 32
-    (1, 70, 70, 256, 320, 3, 1, "same"),     # 256-wide tiles of the LDS-DMA implicit GEMM (M = 4900, N = 320)
-    (2, 38, 38, 64, 128, 3, 2, "same"),      # stride-2 data gradient by parity classes (even size, pad (0,1))
-    (3, 19, 19, 128, 64, 3, 2, "same"),      # stride-2 data gradient by parity classes (odd size, pad (1,1))
-    (2, 19, 19, 128, 192, 3, 1, "same"),     # weight gradient with 10x24 blocks (the 19x19 maps)
-    (1, 25, 20, 64, 64, 3, 1, "same"),       # 10x24 blocks, partial in both dims
-    (3, 19, 19, 256, 320, 1, 1, "same"),     # 256x256 GEMM weight gradient, pointwise, ragged channel tile
-    (2, 21, 21, 64, 264, 3, 2, "same"),      # 256x256 GEMM weight gradient, strided 3x3 (taps inside a column tile)
-    (5, 3, 3, 128, 256, 3, 1, "valid"),      # 256x256 GEMM weight gradient, VALID, tiny M
-    (2, 38, 38, 64, 192, 3, 1, "same"),      # LDS-patch kernel on strip blocks (narrow map, N > 128)
-    (3, 19, 19, 128, 320, 3, 1, "same"),     # strip blocks spanning images, two channel chunks x three channel tiles
-    (5, 70, 45, 64, 64, 3, 1, "same"),       # 64 -> 64 kernel (weights in registers, persistent), ragged blocks
-]
+from tests.conv_cases import CASES, FIRST_LAYER_CASE, FULL_SIZE_CASES, plan_names          # noqa: E402  (shared with the CPU coverage test)
 
 
 def geometry(ops, H, W, k, stride, mode):
@@ -65,12 +41,13 @@ def geometry(ops, H, W, k, stride, mode):
     return Ho, Wo, pt, pl
 
 
-@pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
+@pytest.mark.parametrize("case", CASES, ids=[str(c[:8]) for c in CASES])
 def test_conv_fwd_bwd(ops, case):
-    B, H, W, Cin, Cout, k, stride, mode = case
+    B, H, W, Cin, Cout, k, stride, mode = case[:8]
+    assert plan_names(case[:8]) == case[8], "the dispatch rules moved: this case no longer tests the kernels it names"
     Ho, pt = geometry(ops, H, H, k, stride, mode)[0], geometry(ops, H, H, k, stride, mode)[2]
     Wo, pl = geometry(ops, W, W, k, stride, mode)[0], geometry(ops, W, W, k, stride, mode)[2]
-    g = torch.Generator().manual_seed(hash(case) % 1000)
+    g = torch.Generator().manual_seed(hash(case[:8]) % 1000)
     x = torch.randn((B, H, W, Cin), generator=g).bfloat16()
     w = (torch.randn((Cout, k, k, Cin), generator=g) / np.sqrt(k * k * Cin)).bfloat16()
     bias = torch.randn((Cout,), generator=g) * 0.1
@@ -113,10 +90,55 @@ def test_conv_fwd_bwd(ops, case):
     assert torch.equal(dw, dw2)
 
 
+@pytest.mark.parametrize("case", FULL_SIZE_CASES, ids=[str(c[:8]) for c in FULL_SIZE_CASES])
+def test_conv_full_size_dispatch(ops, case):
+    """The kernels that only large problems reach -- the 8-phase 256x256 implicit GEMM, the 256-row LDS-DMA tiles, the
+    256x256 weight-gradient GEMM, split-K + finalize and the wide split reduction at the network's real K -- against
+    the fp32 reference with the same bounds as the small cases: forward, data gradient (plain, and ReLU mask +
+    accumulation), weight and bias gradient.  Most shapes are layers of the batch-64 SSD300 step itself.  The expected
+    kernels are asserted through the library's dispatch query first, so a future tile-rule change cannot silently
+    orphan a case (tests/test_conv_plan_cpu.py checks the other direction: every kernel of the batch-64 step has a case)."""
+    B, H, W, Cin, Cout, k, stride, mode = case[:8]
+    assert plan_names(case[:8]) == case[8]
+    Ho, Wo, pt, pl = geometry(ops, H, W, k, stride, mode)
+    cp = (Cout + 7) // 8 * 8                                  # head gradients arrive channel-padded
+    g = torch.Generator().manual_seed(B * 7 + Cin + Cout)
+    x = torch.randn((B, H, W, Cin), generator=g).bfloat16()
+    w = (torch.randn((Cout, k, k, Cin), generator=g) / np.sqrt(k * k * Cin)).bfloat16()
+    bias = torch.randn((Cout,), generator=g) * 0.1
+    dy = torch.zeros((B, Ho, Wo, cp), dtype=torch.bfloat16)
+    dy[..., :Cout] = torch.randn((B, Ho, Wo, Cout), generator=g).bfloat16()
+    xd, wd, bd, dyd = x.cuda(), w.cuda(), bias.cuda(), dy.cuda()
+    y = ops.conv2d_fwd(xd, wd, bd, stride, pt, pl, Ho, Wo, True).float().cpu()
+    xr = x.float().requires_grad_(True)
+    wr = w.float().requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    yr = ref_conv(xr, wr, br, k, stride, pt, pl, Ho, Wo, False)
+    err = (y - yr.detach().relu()).abs().max().item()
+    assert err <= 2 ** -7 * max(1.0, yr.abs().max().item()), ("fwd", err)
+    yr.backward(dy[..., :Cout].float())
+    del yr, y
+    w_t = ops.weight_transpose(wd, cp)
+    dx = ops.conv2d_bwd_data(dyd, w_t, None, (B, H, W, Cin), stride, pt, pl).float().cpu()
+    scale = max(1.0, xr.grad.abs().max().item())
+    assert (dx - xr.grad).abs().max().item() <= 2 ** -7 * scale, "dgrad"
+    mask_src = torch.randn((B, H, W, Cin), generator=g).bfloat16()
+    base = torch.randn((B, H, W, Cin), generator=g).bfloat16()
+    acc = base.clone().cuda()
+    ops.conv2d_bwd_data(dyd, w_t, mask_src.cuda(), (B, H, W, Cin), stride, pt, pl, accumulate=True, out=acc)
+    want = (xr.grad + base.float()) * (mask_src.float() > 0)
+    assert (acc.float().cpu() - want).abs().max().item() <= 2 ** -6 * max(1.0, want.abs().max().item()), "dgrad+mask+acc"
+    dw, db = ops.conv2d_bwd_weight(xd, dyd, Cout, k, stride, pt, pl)
+    ws = max(1.0, wr.grad.abs().max().item())
+    assert (dw.cpu() - wr.grad).abs().max().item() <= 1e-3 * ws, "wgrad"
+    assert (db.cpu() - br.grad).abs().max().item() <= 1e-3 * max(1.0, br.grad.abs().max().item()), "bias grad"
+
+
 def test_first_layer_kernels_full_size(ops):
     """The dedicated image-layer kernels (8 padded channels -> 64) at the real map size: more blocks than persistent
     workgroups (several iterations per workgroup), ragged right/bottom blocks, forward and weight gradient."""
     B, H, Cin, Cout = 4, 300, 8, 64
+    assert FIRST_LAYER_CASE[:5] == (B, H, H, Cin, Cout) and plan_names(FIRST_LAYER_CASE[:8]) == FIRST_LAYER_CASE[8]
     g = torch.Generator().manual_seed(21)
     x = torch.zeros((B, H, H, Cin)).bfloat16()
     x[..., :3] = torch.randn((B, H, H, 3), generator=g).bfloat16()

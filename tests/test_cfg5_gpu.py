@@ -1,0 +1,124 @@
+"""GPU: BASELINE.json configs[4]'s anchor side -- 24 564 default boxes (grids 64,32,16,8,4,2,1 with 4,6,6,6,6,4,4 boxes per
+cell) through ssd_priors -> ssd_match_encode -> ssd_loss_fwd_bwd -> ssd_score_decode -> ssd_nms,
+against the oracle with the same bounds as at 8732 anchors: priors / match indices / classes / masks / NMS keep masks
+bit-exact, encodings <= 1 ulp, loss 1e-4 relative, scores 2e-6.
+
+PARITY UNPINNED: there is no reference counterpart -- the reference hard-codes 300 / 8732 (models/ssd_model.py:46,75-77,
+153,176-177) and its _build_prior_box indexes s_k_refer[index + 1] in a 7-entry list, so it cannot produce 7 levels.  The
+oracle is the same restatement that is pinned bit-exactly at 8732 anchors, run on the generalised geometry."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import ssd_oracle as O                                   # noqa: E402
+from tests.test_match_gpu import ulp_diff_f32                        # noqa: E402
+
+GRIDS = ((64, 64), (32, 32), (16, 16), (8, 8), (4, 4), (2, 2), (1, 1))
+RATIOS = ((2,), (2, 3), (2, 3), (2, 3), (2, 3), (2,), (2,))
+S_REF = (20, 51, 133, 215, 297, 379, 461, 543)
+IN_SIZE = 512
+A5 = 24564
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import ssd_object_detection_amd.ops as ops_
+    return ops_
+
+
+@pytest.fixture(scope="module")
+def pset(ops):
+    return ops.build_priors(grids=GRIDS, s_ref=S_REF, ratios=RATIOS, in_size=IN_SIZE)
+
+
+@pytest.fixture(scope="module")
+def pri():
+    return O.priors(GRIDS, S_REF, RATIOS, IN_SIZE)
+
+
+def test_priors_bit_exact(pset, pri):
+    assert pset.A == A5 == pri.shape[0]
+    assert np.array_equal(pset.priors.cpu().numpy().view(np.uint64), pri.view(np.uint64))
+
+
+def _conflict_heavy(rng, n_t):
+    """Many gts crowded onto a few coarse cells: rows share their best prior, phase 1 has to run its literal order."""
+    centres = rng.uniform(0.3, 0.7, (max(1, n_t // 6), 2))
+    c = centres[rng.integers(0, len(centres), n_t)] + rng.normal(0, 0.004, (n_t, 2))
+    wh = np.exp(rng.uniform(np.log(0.2), np.log(0.6), (max(1, n_t // 6), 2)))[rng.integers(0, max(1, n_t // 6), n_t)]
+    wh = wh * rng.uniform(0.97, 1.03, (n_t, 2))
+    return np.concatenate([c, wh], 1).astype(np.float32)
+
+
+def test_match_encode_bit_exact(ops, pset, pri):
+    from ssd_object_detection_amd.data_loaders.synthetic import synth_gt
+    rng = np.random.default_rng(55)
+    cls_l, box_l = [], []
+    for i, n_t in enumerate((1, 7, 93, 32, 0, 64)):                       # ragged batch incl. an empty image and the maximum
+        if n_t == 0:
+            cls_l.append(np.zeros((0,), np.float32)); box_l.append(np.zeros((0, 4), np.float32))
+        elif i % 2:
+            box_l.append(_conflict_heavy(rng, n_t)); cls_l.append(rng.integers(0, 80, n_t).astype(np.float32))
+        else:
+            c, b = synth_gt(8000 + i, n_t)
+            cls_l.append(c); box_l.append(b)
+    gt = ops.pack_gt(box_l, cls_l)
+    owner = torch.empty((len(cls_l), A5), dtype=torch.int32, device="cuda")
+    cls, loc, mask = ops.match_encode(*gt, pset, 0.5, owner=owner)
+    cls, loc, mask, owner = cls.cpu().numpy(), loc.cpu().numpy(), mask.cpu().numpy().astype(bool), owner.cpu().numpy()
+    enc0 = O.encode(np.zeros((A5, 4), np.float32), pri).astype(np.float32)
+    for i, (c, b) in enumerate(zip(cls_l, box_l)):
+        if len(c) == 0:
+            assert not mask[i].any() and (cls[i] == 0).all()
+            continue
+        literal = len(c) <= 32                                             # the literal two-phase loop is O(n_pos * n_t * A)
+        rc, rb, rm = (O.match_literal if literal else O.match_closed_form)(c, b, pri, 0.5)
+        assert np.array_equal(mask[i], rm) and np.array_equal(cls[i], rc), i
+        assert (owner[i][~rm] == -1).all()
+        got_box = np.zeros((A5, 4), np.float32)
+        got_box[rm] = b[owner[i][rm]]
+        assert np.array_equal(got_box.view(np.uint32), rb.astype(np.float32).view(np.uint32)), i
+        enc = O.encode(rb, pri).astype(np.float32)
+        enc[~rm] = enc0[~rm]
+        assert np.array_equal(loc[i][:, :2].view(np.uint32), enc[:, :2].view(np.uint32)), i
+        assert ulp_diff_f32(loc[i][:, 2:], enc[:, 2:]).max() <= 1, i
+        assert rm.sum() >= len(c)                                          # every gt owns at least one anchor
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_loss_vs_oracle(ops, pset, dtype):
+    from ssd_object_detection_amd.data_loaders.synthetic import synth_batch_gt
+    B = 3
+    cls_l, box_l = synth_batch_gt(8100, B)
+    gt = ops.pack_gt(box_l, cls_l)
+    cls, gloc, mask = ops.match_encode(*gt, pset, 0.5)
+    g = torch.Generator().manual_seed(3)
+    conf = torch.randn((B, A5, 81), generator=g).to(dtype).cuda()
+    loc = (torch.randn((B, A5, 4), generator=g) * 0.5).to(dtype).cuda()
+    from tests.test_loss_gpu import run_case
+    out, ref = run_case(ops, conf, loc, cls, gloc, mask)              # the bounds of tests/test_loss_gpu.py, unchanged
+    assert int(out[4]) == int(mask.sum()) > 0
+
+
+def test_score_decode_nms_vs_oracle(ops, pset, pri):
+    from tests.test_detect_gpu import synth_logits
+    B = 3
+    conf_np, loc_np = synth_logits(B, A5, 81, 400, 21)
+    conf, loc = torch.from_numpy(conf_np).cuda(), torch.from_numpy(loc_np).cuda()
+    score, cls, box, cand = ops.score_decode(conf, loc, pset, 0.3, float(IN_SIZE))
+    keep = ops.nms(score, cls, box, cand, 0.45, 400)
+    score, cls, box, cand, keep = (t.cpu().numpy() for t in (score, cls, box, cand, keep))
+    s_ref, c_ref, cand_ref = O.score(conf_np, 0.3)
+    np.testing.assert_allclose(score, s_ref, rtol=2e-6, atol=1e-9)
+    p_bg = np.exp(O._log_softmax(conf_np))[..., -1]
+    border = (np.abs(s_ref - 0.3) < 1e-6) | (np.abs(p_bg - 0.3) < 1e-6)
+    cand = cand.astype(bool)
+    assert np.array_equal(cand[~border], cand_ref[~border]) and cand.sum() > 100 * B
+    assert np.array_equal(cls[cand], c_ref[cand])
+    np.testing.assert_allclose(box[cand], O.decode(loc_np, pri[None], IN_SIZE)[cand], rtol=3e-7, atol=0)
+    for i in range(B):                                                     # NMS on identical inputs: bit-exact keep mask
+        want = O.nms(score[i], cls[i], box[i], cand[i], 0.45, 400)
+        assert np.array_equal(keep[i].astype(bool), want), i
+        assert 0 < want.sum() < cand[i].sum()

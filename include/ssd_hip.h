@@ -60,12 +60,22 @@ int ssd_priors(const int* grid_hw, int levels, const double* s_ref, const int* r
 
 /* Geometry of a prior set made by ssd_priors (levels <= SSD_MAX_LEVELS). */
 #define SSD_MAX_LEVELS 8
+#define SSD_GRID_VERIFIED 0x5D5D0001
 typedef struct {
     int levels;
     int grid_h[SSD_MAX_LEVELS];
     int grid_w[SSD_MAX_LEVELS];
     int per_cell[SSD_MAX_LEVELS]; /* priors per cell = 2 + 2*len(ratios[level]) */
+    int verified;                 /* SSD_GRID_VERIFIED once ssd_prior_grid_verify has checked it against a prior array; else 0 */
 } ssd_prior_grid;
+
+/* Check on the device that `grid` describes `priors` exactly: every prior at the cell centre ssd_priors computes, bit for
+ * bit, in the reference's order, with one (w, h) per level and anchor type.  Sets grid->verified (HOST) accordingly and
+ * returns SSD_OK either way; synchronises `stream` once -- call it when the prior set is built, not per step.
+ *   scratch DEVICE int32[1].
+ * ssd_match_encode takes its single-launch path only with a verified grid; a grid that was not verified (or does not fit)
+ * is a pruning hint only and can never change a result. */
+int ssd_prior_grid_verify(const double* priors, int A, ssd_prior_grid* grid, int32_t* scratch, void* stream);
 
 /* Encoding of an all-zero (unmatched) target row against every prior: the value
  * apply_anchor_box (utils/bbox.py:94-101) produces for rows match_bbox left at 0, cast to f32 as
@@ -84,15 +94,18 @@ int ssd_encode_zero(const double* priors, int A, float* enc_zero, void* stream);
  *   gt_off   int32[B+1]         image b owns rows gt_off[b] .. gt_off[b+1]-1   (DEVICE)
  *   total_gt, max_nt            HOST-known sum / max of per-image counts (max_nt <= A else SSD_ERR_ASSERT, :50)
  *   priors   double[A*4]; enc_zero float[A*4] from ssd_encode_zero
- *   grid     HOST, may be NULL.  Optional speed hint: the geometry `priors` was generated with
- *            (ssd_priors).  It only seeds a pruning bound; results are identical with, without
- *            or with a wrong hint.
+ *   grid     HOST, may be NULL.  Optional: the geometry `priors` was generated with (ssd_priors).  Verified
+ *            (ssd_prior_grid_verify) it selects the single-launch path, which enumerates the columns that can matter to
+ *            a gt row from the geometry; unverified it only seeds a pruning bound.  Results are identical with,
+ *            without or with a wrong hint.
  *   thresh   > 0 else SSD_ERR_ASSERT (:51)
  *   out_cls  int32[B*A]   (0 where unmatched -- not the background id, as in the reference)
  *   out_loc  float[B*A*4] encoded offsets (finite "zero-row" values where unmatched, as in the reference)
  *   out_mask uint8[B*A]   1 = positive
  *   out_owner int32[B*A] or NULL: the matched gt row of each anchor within its image (-1 = unmatched),
  *            i.e. index_list of utils/bbox.py:60-79 as a dense map.  The training path passes NULL.
+ *   ws       scratch of >= ssd_match_encode_workspace_bytes(B, A, total_gt) bytes (used by the three-launch path only:
+ *            no verified grid, or an image with more than 64 boxes); no state is kept in it.
  * Anchor indices / classes / masks are bit-exact with the reference; out_loc is bit-exact in
  * the division terms and <= 1 float32 ulp in the log terms (device log vs numpy log).
  * ---------------------------------------------------------------------------------------- */

@@ -17,7 +17,8 @@ class PriorGrid(ctypes.Structure):
     _fields_ = [("levels", ctypes.c_int),
                 ("grid_h", ctypes.c_int * SSD_MAX_LEVELS),
                 ("grid_w", ctypes.c_int * SSD_MAX_LEVELS),
-                ("per_cell", ctypes.c_int * SSD_MAX_LEVELS)]
+                ("per_cell", ctypes.c_int * SSD_MAX_LEVELS),
+                ("verified", ctypes.c_int)]
 
 
 _SIGNATURES = {
@@ -26,6 +27,7 @@ _SIGNATURES = {
     "ssd_priors_count": (ctypes.c_int, [_c_int_p, ctypes.c_int, _c_int_p]),
     "ssd_priors": (ctypes.c_int, [_c_int_p, ctypes.c_int, _c_double_p, _c_int_p, _c_int_p, ctypes.c_double, VP, VP]),
     "ssd_encode_zero": (ctypes.c_int, [VP, ctypes.c_int, VP, VP]),
+    "ssd_prior_grid_verify": (ctypes.c_int, [VP, ctypes.c_int, ctypes.POINTER(PriorGrid), VP, VP]),
     "ssd_match_encode_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "ssd_match_encode": (ctypes.c_int, [VP, VP, VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, VP, VP, ctypes.c_int,
                                         ctypes.POINTER(PriorGrid), ctypes.c_double, VP, VP, VP, VP, VP, ctypes.c_size_t, VP]),

@@ -14,3 +14,6 @@ static inline size_t ssd_align_up(size_t x, size_t a) { return (x + a - 1) / a *
 
 // 64-lane wavefront helpers (gfx950: wave64 only)
 #define SSD_WAVE 64
+
+// Development overrides (ssd_dev_knob, include/ssd_hip.h); defined in conv.hip.  Never set by the product.
+int ssd_knob(const char* name, int dflt);

@@ -3032,7 +3032,7 @@ Knob g_knobs[] = {{"SSD_ABLATE", {KNOB_UNSET}}, {"SSD_DGRAD_S2", {KNOB_UNSET}}, 
                   {"SSD_WGRAD_PATCH_SHAPE", {KNOB_UNSET}}, {"SSD_WGRAD_TILE", {KNOB_UNSET}}, {"SSD_CONV_PATCH_FORM", {KNOB_UNSET}},
                   {"SSD_CONV_PATCH_FLAT", {KNOB_UNSET}}, {"SSD_WGRAD_FIRST", {KNOB_UNSET}}, {"SSD_CONV_FIRST", {KNOB_UNSET}},
                   {"SSD_WGRAD_PATCH_XCD", {KNOB_UNSET}}, {"SSD_CONV_C64", {KNOB_UNSET}}, {"SSD_CONV_POOL_FUSE", {KNOB_UNSET}},
-                  {"SSD_CONV_PATCH_ROWFLAT", {KNOB_UNSET}}, {"SSD_CONV_PW", {KNOB_UNSET}}};
+                  {"SSD_CONV_PATCH_ROWFLAT", {KNOB_UNSET}}, {"SSD_CONV_PW", {KNOB_UNSET}}, {"SSD_MATCH_FUSED", {KNOB_UNSET}}};
 Knob* find_knob(const char* name) {
     for (Knob& k : g_knobs) if (!strcmp(k.name, name)) return &k;
     return nullptr;
@@ -3287,6 +3287,8 @@ bool geom_ok(int B, int H, int W, int C, int Ho, int Wo, int N, int K) {
 }
 
 }  // namespace
+
+int ssd_knob(const char* name, int dflt) { return knob(name, dflt); }
 
 extern "C" {
 

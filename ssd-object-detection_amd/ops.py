@@ -36,6 +36,15 @@ class PriorSet:
         self.grid = grid                # _lib.PriorGrid or None
         self.A = priors.shape[0]
 
+    def verify_grid(self):
+        """Check the geometry against the prior array on the device (one host sync, at build time): a verified grid lets
+        ssd_match_encode take its single-launch path.  Returns whether it was verified."""
+        if self.grid is None:
+            return False
+        scratch = torch.zeros((1,), dtype=torch.int32, device=self.priors.device)
+        _lib.check(_lib.lib().ssd_prior_grid_verify(_ptr(self.priors), self.A, ctypes.byref(self.grid), _ptr(scratch), _stream()))
+        return self.grid.verified != 0
+
 
 def make_grid(grids, ratios):
     g = _lib.PriorGrid()
@@ -72,11 +81,13 @@ def prior_set_from(priors, grid=None):
     A = priors.shape[0]
     enc0 = torch.empty((A, 4), dtype=torch.float32, device=priors.device)
     _lib.check(L.ssd_encode_zero(_ptr(priors), A, _ptr(enc0), _stream()))
-    return PriorSet(priors, enc0, grid)
+    ps = PriorSet(priors, enc0, grid)
+    ps.verify_grid()
+    return ps
 
 
 class MatchWorkspace:
-    """Caller-owned scratch for ssd_match_encode, grown on demand."""
+    """Caller-owned scratch, grown on demand."""
 
     def __init__(self):
         self.buf = None

@@ -100,6 +100,7 @@ def test_wrong_hint_is_harmless(ops, pset):
     gt_box, gt_cls, gt_off, total, max_nt = ops.pack_gt([c["gt_box"] for _, c in cases],
                                                         [c["gt_cls"] for _, c in cases])
     ps = ops.PriorSet(pset.priors, pset.enc_zero, bad)
+    assert ps.verify_grid() is False                             # a wrong geometry is never trusted for more than a bound
     owner = torch.empty((len(cases), pset.A), dtype=torch.int32, device="cuda")
     cls, loc, mask = ops.match_encode(gt_box, gt_cls, gt_off, total, max_nt, ps, 0.5, owner=owner)
     cls, loc, mask, owner = cls.cpu().numpy(), loc.cpu().numpy(), mask.cpu().numpy(), owner.cpu().numpy()
@@ -197,3 +198,54 @@ def test_error_codes(ops, pset):
         ops.match_encode(gt_box, gt_cls, gt_off, total, max_nt, pset, thresh=0.0)
     with pytest.raises(AssertionError):
         ops.match_encode(gt_box, gt_cls, gt_off, total, pset.A + 1, pset, thresh=0.5)
+
+
+def test_single_launch_path_equals_three_launch_path(ops, pset):
+    """The single-launch path (every workgroup resolves its image's phase 1 itself from geometric windows, DESIGN.md
+    section 5) against the three-launch path (lists in memory, separate phase-1 pass), bit for bit: batches of up to 700
+    images, COCO-shaped and heavy box counts up to the path's limit of 64 per image, crowded boxes that force the literal
+    phase-1 order, and the grid's verification flag deciding the path."""
+    from ssd_object_detection_amd import _lib
+    from ssd_object_detection_amd.data_loaders.synthetic import synth_batch_gt
+    from tests.test_cfg5_gpu import _conflict_heavy
+    L = _lib.lib()
+    assert pset.grid.verified != 0
+    rng = np.random.default_rng(12)
+    try:
+        for it, (B, nt) in enumerate([(64, None), (256, None), (700, None), (64, 64), (33, 40), (9, 57), (512, None), (128, 17), (40, -1)]):
+            if nt == -1:                                       # crowded boxes: shared best priors, exhausted candidate chains
+                box_l = [_conflict_heavy(rng, int(rng.integers(2, 64))) for _ in range(B)]
+                cls_l = [rng.integers(0, 80, len(b)).astype(np.float32) for b in box_l]
+            else:
+                cls_l, box_l = synth_batch_gt(int(rng.integers(0, 5000)), B, nt)
+                cls_l, box_l = [c[:64] for c in cls_l], [b[:64] for b in box_l]
+            gt = ops.pack_gt(box_l, cls_l)
+            outs = {}
+            for path in (1, 0):
+                L.ssd_dev_knob(b"SSD_MATCH_FUSED", path)
+                owner = torch.full((B, pset.A), -9, dtype=torch.int32, device="cuda")
+                got = ops.match_encode(*gt, pset, 0.5, owner=owner)
+                outs[path] = [t.clone() for t in got] + [owner]
+            for name, a, b in zip(("cls", "loc", "mask", "owner"), outs[0], outs[1]):
+                assert torch.equal(a, b), (it, B, nt, name, int((a != b).sum()))
+    finally:
+        L.ssd_dev_knob(b"SSD_MATCH_FUSED", 0)
+
+
+def test_grid_verification(ops, pset):
+    """ssd_prior_grid_verify accepts exactly the geometry the priors were generated with: a wrong grid, a permuted prior
+    array or a perturbed prior are refused (and then the hint can only seed a pruning bound)."""
+    from ssd_object_detection_amd import _lib
+    assert pset.verify_grid() is True
+    bad = _lib.PriorGrid()
+    bad.levels = 3
+    for i, (h, w, k) in enumerate([(7, 5, 3), (40, 40, 5), (2, 9, 1)]):
+        bad.grid_h[i], bad.grid_w[i], bad.per_cell[i] = h, w, k
+    assert ops.PriorSet(pset.priors, pset.enc_zero, bad).verify_grid() is False
+    pri = pset.priors.clone()
+    pri[4000, 0] = pri[4000, 0] * (1 + 2.0 ** -52)             # one ulp off the cell centre
+    ps = ops.PriorSet(pri, pset.enc_zero, ops.make_grid(ops.SSD300_GRIDS, ops.SSD300_RATIOS))
+    assert ps.verify_grid() is False and ps.grid.verified == 0
+    pri = pset.priors.clone()
+    pri[[10, 11]] = pri[[11, 10]]                                # two anchor types of one cell swapped
+    assert ops.PriorSet(pri, pset.enc_zero, ops.make_grid(ops.SSD300_GRIDS, ops.SSD300_RATIOS)).verify_grid() is False

@@ -106,6 +106,7 @@ class SSDObjectDetectionModel:
         rank, world = shard if shard is not None else self._rank_world()
         assert batch_size % world == 0, "the global batch must divide evenly over the ranks"
         lo, hi = shard_range(batch_size, rank, world)
+        raw = bool(getattr(dataset, "raw", False))     # reader-contract samples: /255, resize, box normalisation on the device
 
         class _Batches:
             def __iter__(self_inner):
@@ -119,10 +120,10 @@ class SSDObjectDetectionModel:
                         imgs, clss, boxes = [], [], []
                         for t in mine:
                             image, cls, box = t()
-                            imgs.append(np.asarray(image, np.float32))
+                            imgs.append(np.asarray(image) if raw else np.asarray(image, np.float32))
                             clss.append(np.asarray(cls, np.float32))
                             boxes.append(np.asarray(box, np.float32))
-                        yield model.make_batch(imgs, clss, boxes)
+                        yield model.make_batch_raw(imgs, clss, boxes) if raw else model.make_batch(imgs, clss, boxes)
                         mine, pos = [], 0
 
         return _Batches()

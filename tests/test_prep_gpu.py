@@ -70,3 +70,45 @@ def test_train_step_from_raw_inputs():
     _, _, info = model._train_step(x, cls, loc, mask, optimizers.Adam(1e-3))
     vals = [float(info[k]) for k in ("loc loss", "cls loss pos", "cls loss neg")]
     assert all(np.isfinite(v) and v > 0 for v in vals)
+
+
+def test_reader_contract_source_through_the_loader(tmp_path):
+    """The `_coco2ssd` seam (reference data_loaders/ssd/make_dataset.py:37-46): any object with the COCO reader's contract
+    -- get_dataset() -> iterables of (imread / 255 image, cls, centre-form pixel boxes) -- goes through SSDDataLoader and
+    get_train_set into the device-side preprocessing, and yields exactly what make_batch_raw gives for the decoded samples;
+    one epoch of train() runs on it."""
+    from ssd_object_detection_amd import optimizers
+    from ssd_object_detection_amd.data_loaders import SSDDataLoader
+    from ssd_object_detection_amd.data_loaders.synthetic import synth_raw_sample
+    from ssd_object_detection_amd.models import SSDObjectDetectionModel
+
+    class Reader:                                            # what COCODataLoader.gen yields (reference coco/make_dataset.py:108-134)
+        def _gen(self, first, n):
+            for i in range(first, first + n):
+                img, cls, tlwh = synth_raw_sample(i)
+                box = tlwh.copy()
+                box[:, :2] += box[:, 2:] / 2                  # :132
+                yield (img / 255 if i % 2 else img), cls, box    # float in [0,1] as imread / 255, or still uint8
+
+        def get_dataset(self):
+            return list(self._gen(0, 9)), list(self._gen(100, 3))
+
+    loader = SSDDataLoader("unused", dataset=Reader(), mini_batch=8)
+    train, val = loader.get_dataset()
+    assert len(loader.get_names_and_colors()[0]) == 80 and getattr(train, "raw", False)
+    model = SSDObjectDetectionModel(classes=80, log_dir=str(tmp_path), seed=2, timestamp_dir=False)
+    batches = list(model.get_train_set(train, batch_size=4))
+    assert len(batches) == 2                                 # mini_batch = 8 of the 9 samples, batch 4
+    samples = [synth_raw_sample(i) for i in range(4)]
+    imgs, cls_l, box_l = zip(*samples)
+    x_ref, (cls_ref, loc_ref, mask_ref) = model.make_batch_raw(list(imgs), list(cls_l), list(box_l))
+    x, (cls, loc, mask) = batches[0]
+    assert x.dtype == torch.bfloat16 and torch.equal(x, x_ref)
+    assert torch.equal(cls, cls_ref) and torch.equal(mask, mask_ref)
+    assert float((loc - loc_ref).abs().max()) <= 2e-5        # centre -> top-left -> centre costs an ulp of a pixel coordinate
+    cfg = SSDObjectDetectionModel.TrainConfig(epoch=1, batch_size=4, optimizer=optimizers.Adam(1e-3), warmup=False)
+    model.train(loader, cfg)
+    assert float(model.last_info["status"]) == 0.0
+    import pytest as _pt
+    with _pt.raises(ValueError):
+        SSDDataLoader("unused", dataset=object())           # not a reader, not a known name (reference :33)

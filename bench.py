@@ -393,7 +393,29 @@ def cfg5_section(torch, ops, B):
     t_nms = graph_timed(torch, lambda: ops.nms(score, dcls, box, cand, 0.45, 400), 20)
     mbytes = B * A * MATCH_BYTES_PER_ANCHOR + 20 * gt[3]
     lbytes = B * A * (2 * 81 * 2 + 2 * 4 * 2 + 21)
-    return {"config": {"workload": "BASELINE configs[4] anchors: A=%d (grids 64,32,16,8,4,2,1; per cell 4,6,6,6,6,4,4), batch %d, "
+    # the same geometry end to end: the SSD recipe at 512 x 512 with seven levels (engine.SSD512_TRUNK), batch 16
+    from ssd_object_detection_amd.engine import SSDEngine, SSD512_TRUNK, SSD512_NUM_PRIORS
+    Bs = 16
+    eng = SSDEngine(classes=81, in_size=512, trunk=SSD512_TRUNK, num_priors=SSD512_NUM_PRIORS, seed=0)
+    assert eng.A == A
+    img = torch.rand((Bs, 512, 512, 3), device="cuda")
+    gts = ops.pack_gt(box_l[:Bs], cls_l[:Bs])
+    tgt = ops.match_encode(*gts, ps, 0.5)
+
+    def step512():
+        ops.match_encode(*gts, ps, 0.5, out=tgt)
+        x = ops.image_prep(img, normalize=True)
+        ploc, pconf = eng.forward(x)
+        _, dconf, dloc = ops.ssd_loss(pconf, ploc, *tgt)
+        eng.backward(dloc, dconf)
+        eng.clip_scales(0.01)
+        eng.adam(1e-3, eng.grad, 1.0, True)
+    t_step = timed(torch, step512, 5, warm=2)
+    del eng
+    return {"train_step": {"workload": "SSD recipe at 512x512, 7 levels, %d anchors, batch %d, bf16 (VGG-style trunk, engine.SSD512_TRUNK): "
+                                       "match + prep + fwd + loss + bwd + 72-variable clip + Adam" % (A, Bs),
+                           "images_per_sec": round(Bs / t_step, 1), "ms_per_step": round(t_step * 1e3, 3)},
+            "config": {"workload": "BASELINE configs[4] anchors: A=%d (grids 64,32,16,8,4,2,1; per cell 4,6,6,6,6,4,4), batch %d, "
                                    "anchor-side kernels only (no ResNet-50 / fp8 convolutions); no reference counterpart" % (A, B)},
             "match_encode_us_per_image": round(t_match / B * 1e6, 4), "match_GBs": round(mbytes / t_match / 1e9, 1),
             "loss_us_per_image": round(t_loss / B * 1e6, 4), "loss_GBs": round(lbytes / t_loss / 1e9, 1),

@@ -45,6 +45,25 @@ SSD300_TRUNK = [
 SSD300_NUM_PRIORS = (4, 6, 6, 6, 4, 4)           # models/ssd_model.py:153
 IMAGE_CHANNELS = 3
 
+# BASELINE.json configs[4] stress geometry (no reference counterpart: the reference hard-codes 300 / 8732): the same
+# network recipe at 512 x 512 with one more stride-2 stage, 7 feature levels 64, 32, 16, 8, 4, 2, 1 and 4, 6, 6, 6, 6, 4, 4
+# default boxes per cell = 24 564 anchors.  (VGG-style trunk in bf16 -- not the ResNet-50 / fp8 of that config's title.)
+SSD512_TRUNK = SSD300_TRUNK[:13] + [
+    ("conv", 512, 1024, 3, 2, "same", False),    # 64 -> 32
+    ("conv", 1024, 1024, 1, 1, "same", True),    # feature map 1 (32x32x1024)
+    ("conv", 1024, 256, 1, 1, "same", False),
+    ("conv", 256, 512, 3, 2, "same", True),      # feature map 2 (16x16x512)
+    ("conv", 512, 128, 1, 1, "same", False),
+    ("conv", 128, 256, 3, 2, "same", True),      # feature map 3 (8x8x256)
+    ("conv", 256, 128, 1, 1, "same", False),
+    ("conv", 128, 256, 3, 2, "same", True),      # feature map 4 (4x4x256)
+    ("conv", 256, 128, 1, 1, "same", False),
+    ("conv", 128, 256, 3, 2, "same", True),      # feature map 5 (2x2x256)
+    ("conv", 256, 128, 1, 1, "same", False),
+    ("conv", 128, 256, 3, 2, "same", True),      # feature map 6 (1x1x256)
+]
+SSD512_NUM_PRIORS = (4, 6, 6, 6, 6, 4, 4)
+
 
 class ParamTensor:
     """One trainable variable of the reference (= one tf.clip_by_norm unit, models/ssd_model.py:249): `numel` elements at

@@ -122,3 +122,54 @@ def test_score_decode_nms_vs_oracle(ops, pset, pri):
         want = O.nms(score[i], cls[i], box[i], cand[i], 0.45, 400)
         assert np.array_equal(keep[i].astype(bool), want), i
         assert 0 < want.sum() < cand[i].sum()
+
+
+def test_ssd512_style_network_and_train_step(ops, pset, pri):
+    """configs[4]'s geometry end to end: the SSD network recipe at 512 x 512 with seven feature levels (engine.SSD512_TRUNK,
+    24 564 anchors) through the same kernels -- forward / backward against the fp32 torch oracle with the bounds of
+    tests/test_engine_gpu.py, then target assignment, loss (1e-4 vs the f64 oracle), backward, 72-variable clip + Adam.
+    (VGG-style trunk in bf16: the ResNet-50 / fp8 of that config's title has no counterpart here or in the reference.)"""
+    from oracle import net_oracle as N
+    from ssd_object_detection_amd.engine import SSDEngine, SSD512_TRUNK, SSD512_NUM_PRIORS
+    from ssd_object_detection_amd.data_loaders.synthetic import synth_batch_gt
+    from tests.test_engine_gpu import gemm_arrays, oracle_params, rel_l2
+    eng = SSDEngine(classes=81, in_size=IN_SIZE, trunk=SSD512_TRUNK, num_priors=SSD512_NUM_PRIORS, seed=5)
+    assert eng.A == A5 and eng.grids == GRIDS and len(eng.tensors) == 22 * 2 + 7 * 4
+    B = 1
+    g = torch.Generator().manual_seed(4)
+    x = ops.image_prep(torch.rand((B, IN_SIZE, IN_SIZE, 3), generator=g).cuda())
+    loc, conf = eng.forward(x)
+    params = oracle_params(eng, requires_grad=True)
+    loc_r, conf_r = N.forward(SSD512_TRUNK, SSD512_NUM_PRIORS, 81, params, x.float().cpu())
+    assert loc.shape == (B, A5, 4) and conf.shape == (B, A5, 81)
+    assert rel_l2(loc.float().cpu(), loc_r.detach()) < 1e-2 and rel_l2(conf.float().cpu(), conf_r.detach()) < 1e-2
+    # one train step on these predictions
+    cls_l, box_l = synth_batch_gt(8200, B)
+    gcls, gloc, gmask = ops.match_encode(*ops.pack_gt(box_l, cls_l), pset, 0.5)
+    out, dconf, dloc = ops.ssd_loss(conf, loc, gcls, gloc, gmask)
+    ref = O.ssd_loss(gcls.cpu().numpy(), gloc.cpu().numpy(), gmask.cpu().numpy(), loc.float().cpu().numpy(),
+                     conf.float().cpu().numpy(), want_grad=True)
+    o = out.cpu().numpy()
+    assert o[7] == 0 and int(o[4]) == ref["num_pos"] > 0
+    for k, name in enumerate(("loc", "pos", "neg")):
+        assert abs(o[k] - ref[name]) <= 1e-4 * abs(ref[name]), (name, o[k], ref[name])
+    eng.backward(dloc, dconf)
+    (loc_r * dloc.float().cpu()).sum().add((conf_r * dconf.float().cpu()).sum()).backward()
+    gflat = eng.grad.cpu()
+    for t in gemm_arrays(eng):
+        got = gflat[t.offset:t.offset + t.numel].view(t.shape)
+        want = params[t.name].grad
+        if float(want.norm()) == 0.0:
+            assert float(got.norm()) == 0.0, t.name
+            continue
+        err = rel_l2(got, want)
+        cos = float((got * want).sum() / (got.norm() * want.norm() + 1e-30))
+        assert err < (1e-2 if t.name.startswith("head") else 0.15) and cos > 0.985, (t.name, err, cos)
+    p0 = eng.param.clone()
+    eng.clip_scales(0.01)
+    eng.adam(1e-3, eng.grad, 1.0, True)
+    torch.cuda.synchronize()
+    moved = float((eng.param - p0).abs().max())
+    assert 0 < moved < 2e-3 and bool(torch.isfinite(eng.param).all())
+    scales = eng.clip_scale.cpu().numpy()
+    assert scales.shape == (72,) and (scales > 0).all() and (scales <= 1).all()

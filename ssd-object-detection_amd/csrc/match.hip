@@ -511,7 +511,7 @@ __global__ __launch_bounds__(WG) void k_match_phase1(
 //               (min(hP, hG) + 2e-10) - 2e-10, i.e. the prior's centre lies in [g.lx + m_w - wP/2, g.hx - m_w + wP/2]; likewise
 //               in y.  Per (row, anchor type) that is a rectangle of cells (typically 0-9 cells, ~25 per row in all),
 //               queued in LDS one cell per entry.
-//   4. evaluate every queued cell EXACTLY, one per thread and pass (the prior is loaded, iou_n's arithmetic, division only past the
+//   4. evaluate every queued cell EXACTLY, one per thread and pass (the prior comes from the model: the same bits as the array; iou_n's arithmetic, division only past the
 //               division-free filter); pairs with q >= 0.8 L' go to the row's candidate chain in LDS.  The chain holds
 //               every column of the row with IoU >= 0.8 L' -- what the lists of the three-launch path hold.
 //   5. phase 1  the literal order by pivot batching, as phase1_image, on the LDS chains; a row whose chain is exhausted
@@ -522,7 +522,8 @@ __global__ __launch_bounds__(WG) void k_match_phase1(
 constexpr int LOC_MAX_ROWS = 64;
 constexpr int LOC_MAX_TYPES = 48;              // anchor types = sum of per_cell over the levels (SSD300: 30)
 constexpr int LOC_UNITS = 2048;              // window cells per round of LOC_ROUND rows (overflow: the row is scanned exactly)
-constexpr int LOC_ROUND = 16;
+constexpr int LOC_ROUND = 32;
+constexpr int LOC_MAX_CELLS = 256;             // sum of the grid widths (heights) over the levels (SSD300: 76)
 constexpr int LOC_CANDS = 512;
 constexpr int LOC_GROUP = 8;
 
@@ -535,7 +536,9 @@ struct LocalLds {
     int cls[LOC_MAX_ROWS];
     double tw[LOC_MAX_TYPES], th[LOC_MAX_TYPES];           // anchor type t: size,
     int tgw[LOC_MAX_TYPES], tgh[LOC_MAX_TYPES];            //   grid of its level,
-    int tcol[LOC_MAX_TYPES], tk[LOC_MAX_TYPES];            //   column of the type in cell (0, 0), priors per cell
+    int tcol[LOC_MAX_TYPES], tk[LOC_MAX_TYPES];            //   column of the type in cell (0, 0), priors per cell,
+    int tcx[LOC_MAX_TYPES], tcy[LOC_MAX_TYPES];            //   where its level's cell centres start in ccx / ccy
+    double ccx[LOC_MAX_CELLS], ccy[LOC_MAX_CELLS];         // cell centres (x + .5) / gw, (y + .5) / gh of every level: what k_priors stored
     unsigned units[LOC_UNITS];
     LocCand cand[LOC_CANDS];
     int head[LOC_MAX_ROWS];                    // chain head (-1: empty)
@@ -600,16 +603,32 @@ __global__ __launch_bounds__(WG) void k_match_local(
     if (tid < ntypes) {
         // the level of type `tid` with compile-time indices into the kernel argument (a per-lane index would turn every
         // access into a memory load: that alone cost 25 us)
-        int gw = 1, gh = 1, col = 0, k = 1;
+        int gw = 1, gh = 1, col = 0, k = 1, ox = 0, oy = 0, sx = 0, sy = 0;
 #pragma unroll
-        for (int l = 0; l < SSD_MAX_LEVELS; ++l)
+        for (int l = 0; l < SSD_MAX_LEVELS; ++l) {
             if (l < hint.levels && tid >= hint.cand_off[l]) {
                 gw = hint.gw[l]; gh = hint.gh[l]; k = hint.k[l]; col = hint.col_off[l] + tid - hint.cand_off[l];
+                ox = sx; oy = sy;
             }
+            if (l < hint.levels) { sx += hint.gw[l]; sy += hint.gh[l]; }
+        }
         const double2 wh = *reinterpret_cast<const double2*>(priors + 4 * (size_t)col + 2);
         S.tw[tid] = wh.x;
         S.th[tid] = wh.y;
-        S.tgw[tid] = gw; S.tgh[tid] = gh; S.tcol[tid] = col; S.tk[tid] = k;
+        S.tgw[tid] = gw; S.tgh[tid] = gh; S.tcol[tid] = col; S.tk[tid] = k; S.tcx[tid] = ox; S.tcy[tid] = oy;
+    }
+    {   // cell centres of every level, with k_priors' arithmetic: (x + .5) / gw -- the values the verified prior array holds
+        int gwx = 1, x = 0, ghy = 1, y = 0, sx = 0, sy = 0;
+        bool inx = false, iny = false;
+#pragma unroll
+        for (int l = 0; l < SSD_MAX_LEVELS; ++l)
+            if (l < hint.levels) {
+                if (tid >= sx && tid < sx + hint.gw[l]) { gwx = hint.gw[l]; x = tid - sx; inx = true; }
+                if (tid >= sy && tid < sy + hint.gh[l]) { ghy = hint.gh[l]; y = tid - sy; iny = true; }
+                sx += hint.gw[l]; sy += hint.gh[l];
+            }
+        if (inx) S.ccx[tid] = ((double)x + 0.5) / (double)gwx;
+        if (iny) S.ccy[tid] = ((double)y + 0.5) / (double)ghy;
     }
     if (tid == 0) { S.nunits = 0; S.ncand = 0; S.nres = 0; }
     __syncthreads();
@@ -630,7 +649,7 @@ __global__ __launch_bounds__(WG) void k_match_local(
                 int y = (int)floorf(g.y * (float)tgh);
                 x = min(max(x, 0), tgw - 1);
                 y = min(max(y, 0), tgh - 1);
-                const double cx = ((double)x + 0.5) / (double)tgw, cy = ((double)y + 0.5) / (double)tgh;   // k_priors
+                const double cx = S.ccx[S.tcx[t] + x], cy = S.ccy[S.tcy[t] + y];
                 double inter, uni;
                 inter_union(gc, prior_corner(cx, cy, S.tw[t], S.th[t]), inter, uni);
                 const double q = inter / uni;
@@ -660,6 +679,7 @@ __global__ __launch_bounds__(WG) void k_match_local(
             const int tgw = S.tgw[t], tgh = S.tgh[t];
             const double wP = S.tw[t], hP = S.th[t];
             const double T = g.lbm * fmax(wP * hP, g.a) * (1.0 - 1e-6);   // the chain bound 0.8 L': the window of what step 4 keeps
+            if (fmin(wP * hP, g.a) + 4e-10 < T) continue;                  // inter <= min(aP, aG) + 3e-10: this type cannot reach the bound
             const double m_w = T / (fmin(hP, fmax(g.hy - g.ly, 0.0)) + 2e-10) - 2e-10;
             const double m_h = T / (fmin(wP, fmax(g.hx - g.lx, 0.0)) + 2e-10) - 2e-10;
             const double gw = (double)tgw, gh = (double)tgh;
@@ -686,14 +706,14 @@ __global__ __launch_bounds__(WG) void k_match_local(
         for (int u = tid; u < nu; u += WG) {       // one cell per thread and pass: the gathers of a pass are all in flight
             const unsigned w = S.units[u];
             const int r = w & 63, t = (w >> 6) & 63, y = (w >> 12) & 127, x = (w >> 19) & 127;
-            const int col = min(max(S.tcol[t] + (y * S.tgw[t] + x) * S.tk[t], 0), A - 1);   // (in range by construction)
-            const double2 lo = *reinterpret_cast<const double2*>(priors + 4 * (size_t)col);
-            const double2 hi = *reinterpret_cast<const double2*>(priors + 4 * (size_t)col + 2);
+            const int col = S.tcol[t] + (y * S.tgw[t] + x) * S.tk[t];
             const RowRec g = S.rows[r];
             Corner gc;
             gc.lx = g.lx; gc.ly = g.ly; gc.hx = g.hx; gc.hy = g.hy; gc.a = g.a;
             double inter, uni;
-            inter_union(gc, prior_corner(lo.x, lo.y, hi.x, hi.y), inter, uni);
+            // the prior of this cell from the model -- (cx, cy, w, h) are the very values the verified array holds, so no
+            // load (and no memory round trip) is needed to evaluate it exactly
+            inter_union(gc, prior_corner(S.ccx[S.tcx[t] + x], S.ccy[S.tcy[t] + y], S.tw[t], S.th[t]), inter, uni);
             if (inter >= g.lbm * uni) {
                 const double q = inter / uni;
                 if (q >= g.lbm) {
@@ -1097,11 +1117,13 @@ int ssd_match_encode(const float* gt_box, const float* gt_cls, const int32_t* gt
     // SSD_MATCH_FUSED != 0) until its phases are tuned; DESIGN.md section 5 has the numbers.
     bool local = have_hint && grid->verified == SSD_GRID_VERIFIED && hint.col_off[hint.levels] == A && max_nt <= LOC_MAX_ROWS &&
                  hint.cand_off[hint.levels] <= LOC_MAX_TYPES && lds_bitmaps <= 40 * 1024 && ssd_knob("SSD_MATCH_FUSED", 0) != 0;
-    for (int l = 0; local && l < hint.levels; ++l) local = hint.gh[l] <= 128 && hint.gw[l] <= 128;
+    int sum_w = 0, sum_h = 0;
+    for (int l = 0; local && l < hint.levels; ++l) { local = hint.gh[l] <= 128 && hint.gw[l] <= 128; sum_w += hint.gw[l]; sum_h += hint.gh[l]; }
+    local = local && sum_w <= LOC_MAX_CELLS && sum_h <= LOC_MAX_CELLS;
     if (local) {
         const int ngroups = (B + LOC_GROUP - 1) / LOC_GROUP;
         const int knob = ssd_knob("SSD_MATCH_FUSED", 0);
-        const int cpw = (knob & 2) ? 1 : ((knob & 4) ? 2 : 4);        // development: bits 1 / 2 select 1 / 2 columns per thread
+        const int cpw = (knob & 2) ? 4 : ((knob & 4) ? 1 : 2);        // development: bits 1 / 2 select 4 / 1 columns per thread (default 2)
         const int nch = (A + WG * cpw - 1) / (WG * cpw);
 #define SSD_LAUNCH_LOCAL(CPW_)                                                                                         \
         hipLaunchKernelGGL(k_match_local<CPW_>, dim3((unsigned)(ngroups * LOC_GROUP * nch)), dim3(WG), lds_bitmaps, s,   \

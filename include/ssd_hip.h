@@ -203,6 +203,20 @@ int ssd_conv2d_head_fwd(const void* x, const void* w, const float* bias, void* l
 int ssd_conv2d_bwd_data(const void* dy, const void* w_t, const void* relu_src, void* dx, int B, int H, int W, int Cin,
                         int Cout_pad, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int accumulate,
                         void* ws, size_t ws_bytes, void* stream);
+/* Winograd F(2x2,3x3) form of the 3x3 / stride 1 / pad 1 layers (same Conv2D of models/ssd_model.py:74-171 and its
+ * data gradient, 2.25x fewer MACs, fp16 transformed operands with fp32 accumulation; csrc/wino.hip).
+ * ssd_wino_weights: u = G g G^T of w[Cout][3][3][Cin] bf16 (x 2^w_shift), ssd_wino_weights_bytes(Cout, Cin) bytes, once
+ * per weight update; for the data gradient pass ssd_weight_transpose's output with Cout / Cin swapped.
+ * Operands enter fp16 as value * 2^in_shift (exact; keeps small gradients out of fp16's subnormals), the result is
+ * scaled back by 2^-(in_shift + w_shift).  Shapes: Cin % 64 == 0, Cout % 64 == 0, H, W >= 16 (ssd_conv3x3_wino_supported);
+ * anything else returns SSD_ERR_VALUE before a launch.  y == NULL with y_pool != NULL: only the pooled map leaves. */
+size_t ssd_wino_weights_bytes(int Cout, int Cin);
+int ssd_wino_weights(const void* w, void* u, int Cout, int Cin, int w_shift, void* stream);
+int ssd_conv3x3_wino_supported(int B, int H, int W, int Cin, int Cout);
+int ssd_conv3x3_wino_fwd(const void* x, const void* u, const float* bias, void* y, void* y_pool, void* pool_code, int B, int H,
+                         int W, int Cin, int Cout, int relu, int Hp, int Wp, int in_shift, int w_shift, void* stream);
+int ssd_conv3x3_wino_bwd_data(const void* dy, const void* u_t, const void* relu_src, void* dx, int B, int H, int W, int Cin,
+                              int Cout, int accumulate, int in_shift, int w_shift, void* stream);
 /* dw f32 [Cout][k][k][Cin], dbias f32 [Cout] (or NULL) from x[B,H,W,Cin] and dy[B,Ho,Wo,ldy] (first Cout
  * channels).  Deterministic (fixed-order split reduction). */
 size_t ssd_conv2d_bwd_weight_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ldy, int ksize);

@@ -1,0 +1,432 @@
+// Types, geometry, epilogues and host helpers shared by the convolution translation units (conv.hip, wino.hip).
+#pragma once
+#include <atomic>
+#include <type_traits>
+#include "common.h"
+#include <hip/hip_bf16.h>
+
+namespace {
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4_t;
+typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s16x4_t;
+typedef unsigned short bf16_raw;
+
+constexpr int WG = 256;
+
+struct FastDiv {                             // exact n / d for 0 <= n < 2^31
+    unsigned mg;
+    int sh;                                  // sh < 0: d == 1
+    int d;
+};
+
+inline FastDiv make_fastdiv(int d) {
+    FastDiv f;
+    f.d = d;
+    if (d <= 1) { f.mg = 0; f.sh = -1; return f; }
+    int l = 0;
+    while ((1ll << l) < d) ++l;
+    const int s = 31 + l;
+    f.mg = (unsigned)(((1ull << s) + (unsigned long long)d - 1) / (unsigned long long)d);
+    f.sh = s - 32;
+    return f;
+}
+
+__device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
+    return f.sh < 0 ? n : (int)(__umulhi((unsigned)n, f.mg) >> f.sh);
+}
+
+struct ConvGeom {
+    int B, H, W, C;                          // source tensor (NHWC), C % 8 == 0
+    int Ho, Wo, N;                           // destination spatial dims and channel count (GEMM N)
+    int KH, KW;
+    int mul, div, pad_t, pad_l;              // source coordinate = (o*mul + k - pad) / div
+    int M;                                   // B*Ho*Wo
+    int nchunks;                             // KH*KW*C/8  (16-byte k chunks)
+    int ldw;                                 // weight row stride (elements) = KH*KW*C
+    int cpt;                                 // chunks per tap = C/8
+    FastDiv d_hw, d_w;                       // divide by Ho*Wo and by Wo
+    FastDiv d_h1;                            // divide by H + 1 (row strip of k_conv3x3_patch32)
+    // stride-2 data gradient: destination pixels are enumerated parity class by parity class (py,px), each class
+    // padded to whole tiles, so that a tile has ONE parity and the taps that cannot hit it are skipped outright
+    int s2;                                  // 1: parity-class enumeration active (div == 2, cpt % 8 == 0)
+    int cls_n[4];                            // pixels per class (B * cls_h[py] * cls_w[px]), class = 2*py + px
+    int cls_h[2], cls_w[2];
+    int ablate;                              // dev only (SSD_ABLATE): 1 no DMA after the prologue, 2 no wait/barrier, 4 no MFMA
+};
+
+enum { EPI_FWD = 0, EPI_HEAD = 1, EPI_DGRAD = 2 };
+#ifndef SSD_DMA_SLOT
+#define SSD_DMA_SLOT 0                        // 0: issue the next tile's DMA before the MFMAs, 1: between the two MFMA blocks
+#endif
+#ifndef SSD_PT256
+#define SSD_PT256 4                           // pixel tiles per wave of the 256x256 implicit-GEMM tile (8 = 8 waves of 128x64: no faster)
+#endif
+
+struct Epilogue {
+    const float* bias;                       // [N] or null                       (FWD, HEAD)
+    int relu;                                //                                    (FWD)
+    bf16_raw* out;                           // [M][ldo]                           (FWD, DGRAD)
+    int ldo;
+    const bf16_raw* mask_src;                // DGRAD: zero where mask_src <= 0 (ReLU backward), may be null
+    int accumulate;                          // DGRAD: out += result
+    // HEAD: columns [0,n_loc) -> loc, [n_loc, n_loc+n_conf) -> conf, in the reference's concatenated layout
+    bf16_raw* loc;
+    bf16_raw* conf;
+    int n_loc, n_conf;                       // per pixel: n*4 and n*C
+    int anchors_total;                       // A
+    int level_off;                           // first anchor of this level
+    int per_cell;                            // n
+    int classes;                             // C
+    // split-K: when slab != null the kernel stores raw fp32 partial sums to slab[split][M][N] and k_igemm_finalize
+    // applies the epilogue to their fixed-order sum
+    float* slab;
+    int ksplit;
+    // FWD, 16x16-block kernels only: also write the 2x2 / stride-2 max pooling of this layer's output (and the winner
+    // codes of k_maxpool_fwd_argmax), computed from the staged tile: saves the pooling kernel's re-read of the output
+    bf16_raw* pool_out;                      // [B][pool_h][pool_w][N] or null
+    unsigned* pool_code;                     // [B][pool_h][pool_w][N/8]
+    int pool_h, pool_w;
+};
+
+__device__ __forceinline__ float bf2f(bf16_raw v) { return __uint_as_float((unsigned)v << 16); }
+__device__ __forceinline__ bf16_raw f2bf(float f) {
+    const __hip_bfloat16 h = __float2bfloat16(f);
+    return *reinterpret_cast<const bf16_raw*>(&h);
+}
+
+// LDS slot of 16-byte chunk `chunk` (0..7) of tile row `row`: two rows share one 256-byte bank row,
+// slots XOR-swizzled so that 16 consecutive rows reading the same chunk hit 16 different slots.
+__device__ __forceinline__ int swz(int row, int chunk) {
+    return (row >> 1) * 256 + ((((row & 1) << 3) | (chunk ^ ((row >> 1) & 7))) << 4);
+}
+
+// Epilogue shared by the implicit-GEMM kernels: lane holds channels n_base + (lane>>4)*4 + {0..3} of pixel
+// m_base + (lane&15) for every (channel tile, pixel tile) of its wave.
+// Store 4 consecutive output channels n..n+3 of output pixel m (bias already added to v).
+template <int EPI>
+__device__ __forceinline__ void epi_store(float (&v)[4], int m, int n, bool full, const ConvGeom& g, const Epilogue& ep) {
+    if constexpr (EPI == EPI_FWD) {
+        if (ep.relu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        bf16_raw* o = ep.out + (long long)m * ep.ldo + n;
+        if (full) {
+            *reinterpret_cast<uint2*>(o) = make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16),
+                                                      (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (n + j < g.N) o[j] = f2bf(v[j]);
+        }
+    } else if constexpr (EPI == EPI_DGRAD) {
+        bf16_raw* o = ep.out + (long long)m * ep.ldo + n;
+        const bf16_raw* ms = ep.mask_src ? ep.mask_src + (long long)m * ep.ldo + n : nullptr;
+        if (full) {
+            if (ep.accumulate) {
+                const uint2 old = *reinterpret_cast<const uint2*>(o);
+                v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
+                v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
+            }
+            if (ms) {
+                const uint2 mk = *reinterpret_cast<const uint2*>(ms);
+                if (!(__uint_as_float(mk.x << 16) > 0.f)) v[0] = 0.f;
+                if (!(__uint_as_float(mk.x & 0xffff0000u) > 0.f)) v[1] = 0.f;
+                if (!(__uint_as_float(mk.y << 16) > 0.f)) v[2] = 0.f;
+                if (!(__uint_as_float(mk.y & 0xffff0000u) > 0.f)) v[3] = 0.f;
+            }
+            *reinterpret_cast<uint2*>(o) = make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16),
+                                                      (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (n + j >= g.N) continue;
+                float r = v[j];
+                if (ep.accumulate) r += bf2f(o[j]);
+                if (ms && !(bf2f(ms[j]) > 0.f)) r = 0.f;
+                o[j] = f2bf(r);
+            }
+        }
+    } else {  // EPI_HEAD: scatter into loc [B][A][4] and conf [B][A][classes]
+        const int b = fdiv(m, g.d_hw);
+        const int pix = m - b * g.d_hw.d;
+        const long long anchor0 = (long long)b * ep.anchors_total + ep.level_off + (long long)pix * ep.per_cell;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nn = n + j;
+            if (nn >= ep.n_loc + ep.n_conf) continue;
+            if (nn < ep.n_loc) ep.loc[anchor0 * 4 + nn] = f2bf(v[j]);
+            else ep.conf[anchor0 * ep.classes + (nn - ep.n_loc)] = f2bf(v[j]);
+        }
+    }
+}
+
+__device__ __forceinline__ void load_bias4(const Epilogue& ep, int n, int N, bool full, float (&b4)[4]) {
+    b4[0] = b4[1] = b4[2] = b4[3] = 0.f;
+    if (!ep.bias) return;
+    if (full) {
+        const float4 bv = *reinterpret_cast<const float4*>(ep.bias + n);
+        b4[0] = bv.x; b4[1] = bv.y; b4[2] = bv.z; b4[3] = bv.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (n + j < N) b4[j] = ep.bias[n + j];
+    }
+}
+
+template <int EPI, int CT, int PT>
+__device__ __forceinline__ void conv_epilogue_rows(f32x4_t (&acc)[CT][PT], const ConvGeom& g, const Epilogue& ep,
+                                                   const int (&mrow)[PT], int nbase, int lane) {
+    // mrow[p]: flat output pixel of this lane for pixel tile p (-1: outside); nbase: first channel of the wave
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int n = nbase + c * 16 + (lane >> 4) * 4;
+        if (n >= g.N) continue;
+        const bool full = n + 3 < g.N;
+        if (ep.slab) {                           // split-K partial sums (uniform branch)
+            float* sl = ep.slab + (long long)blockIdx.y * g.M * g.N;
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                const int m = mrow[p];
+                if (m < 0) continue;
+                float* o = sl + (long long)m * g.N + n;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (n + j < g.N) o[j] = acc[c][p][j];
+            }
+            continue;
+        }
+        float bias4[4];
+        if constexpr (EPI == EPI_DGRAD) { bias4[0] = bias4[1] = bias4[2] = bias4[3] = 0.f; }
+        else load_bias4(ep, n, g.N, full, bias4);
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            const int m = mrow[p];
+            if (m < 0) continue;
+            float v[4] = {acc[c][p][0] + bias4[0], acc[c][p][1] + bias4[1], acc[c][p][2] + bias4[2], acc[c][p][3] + bias4[3]};
+            epi_store<EPI>(v, m, n, full, g, ep);
+        }
+    }
+}
+
+// Epilogue through LDS: the accumulator layout (a lane holds 4 channels of 16 different pixels) gives 8-byte stores in
+// 32-byte runs (2-byte scattered stores for the head layout); staging the [BM px][BN ch] bf16 tile in LDS first turns
+// them into whole 16-byte chunks of contiguous rows (heads: 64 consecutive elements per wave-instruction).
+// Tile image: BN*2-byte rows, 16-byte chunk index XORed with the row so that both the 8-byte fragment writes and the
+// row-wise reads are (nearly) conflict-free.  Caller guarantees: all waves are past their last LDS read and no LDS-DMA
+// is in flight.  row_to_m(row) -> flat output pixel or -1.
+template <int EPI>
+__device__ __forceinline__ bool staged_ok(const ConvGeom& g, const Epilogue& ep) {
+    if (ep.slab) return false;
+    if constexpr (EPI == EPI_FWD) return (g.N & 7) == 0 && (ep.ldo & 7) == 0;
+    if constexpr (EPI == EPI_DGRAD) return (g.N & 7) == 0 && (ep.ldo & 7) == 0;
+    return true;                                // EPI_HEAD
+}
+
+struct NoPool { __device__ long long operator()(int, int) const { return -1; } };
+
+// Second half of the staged epilogue: the [BM px][BN ch] bf16 tile image in LDS (layout above; FWD: bias and ReLU already
+// applied) leaves as whole 16-byte chunks of contiguous rows; DGRAD applies accumulate / ReLU mask here, FWD the fused pooling.
+// Caller: a barrier between the last write of the image and this call.
+template <int EPI, int BM, int BN, int NT, typename RowMap, typename PoolMap>
+__device__ __forceinline__ void staged_store(char* smem, const ConvGeom& g, const Epilogue& ep, int n0, int tid, RowMap row_to_m,
+                                             PoolMap pool_index) {
+    constexpr int CPR = BN / 8;                 // 16-byte chunks per tile row
+    if constexpr (EPI == EPI_HEAD) {
+        // element-wise, 64 consecutive channels of one pixel per wave-instruction
+        constexpr int ITER = BM * BN / NT;
+        for (int it = 0; it < ITER; ++it) {
+            const int idx = it * NT + tid;
+            const int row = idx / BN, col = idx - row * BN;
+            const int n = n0 + col;
+            const int m = row_to_m(row);
+            if (m < 0 || n >= ep.n_loc + ep.n_conf) continue;
+            const bf16_raw val = *reinterpret_cast<const bf16_raw*>(smem + row * (BN * 2) + ((((col >> 3) ^ row) & (CPR - 1)) << 4) + (col & 7) * 2);
+            const int b = fdiv(m, g.d_hw);
+            const int pix = m - b * g.d_hw.d;
+            const long long anchor0 = (long long)b * ep.anchors_total + ep.level_off + (long long)pix * ep.per_cell;
+            if (n < ep.n_loc) ep.loc[anchor0 * 4 + n] = val;
+            else ep.conf[anchor0 * ep.classes + (n - ep.n_loc)] = val;
+        }
+    } else {
+        constexpr int ITER = BM * CPR / NT;
+        // forward with fused pooling and no consumer of the full-resolution map (out == nullptr): only the pooled map leaves
+        const bool store_full = EPI != EPI_FWD || ep.out != nullptr;
+#pragma unroll 4
+        for (int it = 0; it < (store_full ? ITER : 0); ++it) {
+            const int idx = it * NT + tid;
+            const int row = idx / CPR, ch = idx - row * CPR;
+            const int n = n0 + ch * 8;
+            const int m = row_to_m(row);
+            if (m < 0 || n >= g.N) continue;
+            uint4 v = *reinterpret_cast<const uint4*>(smem + row * (BN * 2) + (((ch ^ row) & (CPR - 1)) << 4));
+            const long long o = (long long)m * ep.ldo + n;
+            if constexpr (EPI == EPI_DGRAD) {
+                if (ep.accumulate) {                          // out += result (two gradients meet at a feature map)
+                    const uint4 old = *reinterpret_cast<const uint4*>(ep.out + o);
+                    auto add2 = [](unsigned a, unsigned b) {
+                        const float lo = __uint_as_float(a << 16) + __uint_as_float(b << 16);
+                        const float hi = __uint_as_float(a & 0xffff0000u) + __uint_as_float(b & 0xffff0000u);
+                        return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+                    };
+                    v.x = add2(v.x, old.x); v.y = add2(v.y, old.y); v.z = add2(v.z, old.z); v.w = add2(v.w, old.w);
+                }
+                if (ep.mask_src) {                            // ReLU backward: zero where the forward activation was <= 0
+                    const uint4 mk = *reinterpret_cast<const uint4*>(ep.mask_src + o);
+                    auto gate = [](unsigned val, unsigned m2) {
+                        if (!(__uint_as_float(m2 << 16) > 0.f)) val &= 0xffff0000u;
+                        if (!(__uint_as_float(m2 & 0xffff0000u) > 0.f)) val &= 0x0000ffffu;
+                        return val;
+                    };
+                    v.x = gate(v.x, mk.x); v.y = gate(v.y, mk.y); v.z = gate(v.z, mk.z); v.w = gate(v.w, mk.w);
+                }
+            }
+            *reinterpret_cast<uint4*>(ep.out + o) = v;
+        }
+        if constexpr (EPI == EPI_FWD && !std::is_same<PoolMap, NoPool>::value) {
+            // fused 2x2 pooling of a 16-wide block tile (rows = 16 y + x, BM / 16 rows): pooled pixel (py, px) <- tile rows
+            // of (2py+dy, 2px+dx)
+            if (ep.pool_out) {
+                for (int idx = tid; idx < (BM / 4) * CPR; idx += NT) {
+                    const int pp = idx / CPR, ch = idx - pp * CPR;
+                    const int py = pp >> 3, px = pp & 7;
+                    const int n = n0 + ch * 8;
+                    const long long po = pool_index(py, px);
+                    if (po < 0 || n >= g.N) continue;
+                    if (ep.relu) {
+                        // after ReLU every candidate is >= +0 (v_max_f32 returns +0 for max(-0, +0)), so bf16 bit patterns
+                        // order like the values: packed 16-bit integer max / compare, two channels per instruction
+                        // (the float form below cost 25 % of block1_conv2's forward time)
+                        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                        uint4 cand[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int row = (2 * py + (q >> 1)) * 16 + 2 * px + (q & 1);
+                            cand[q] = make_uint4(0, 0, 0, 0);      // a position outside the map never wins: 0 only ties with 0 = dead
+                            if (row_to_m(row) >= 0) cand[q] = *reinterpret_cast<const uint4*>(smem + row * (BN * 2) + (((ch ^ row) & (CPR - 1)) << 4));
+                        }
+                        unsigned o4[4], cw = 0;
+                        const us2 one = {1, 1}, four = {4, 4};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const unsigned w0 = (&cand[0].x)[k], w1 = (&cand[1].x)[k], w2 = (&cand[2].x)[k], w3 = (&cand[3].x)[k];
+                            const us2 a = __builtin_bit_cast(us2, w0), b2 = __builtin_bit_cast(us2, w1), c2 = __builtin_bit_cast(us2, w2),
+                                      d2 = __builtin_bit_cast(us2, w3);
+                            const us2 m = __builtin_elementwise_max(__builtin_elementwise_max(a, b2), __builtin_elementwise_max(c2, d2));
+                            const us2 ne0 = __builtin_elementwise_min((us2)(a ^ m), one), ne1 = __builtin_elementwise_min((us2)(b2 ^ m), one),
+                                      ne2 = __builtin_elementwise_min((us2)(c2 ^ m), one);
+                            const us2 t = ne1 * ne2 + ne1;                   // ne1 (1 + ne2)
+                            const us2 first = ne0 * t + ne0;                 // index of the first candidate equal to the max
+                            const us2 alive = __builtin_elementwise_min(m, one);
+                            const us2 code = alive * (us2)(first - four) + four;   // 4 = no winner (max is 0)
+                            o4[k] = __builtin_bit_cast(unsigned, m);
+                            const unsigned cu = __builtin_bit_cast(unsigned, code);
+                            cw |= ((cu & 0xfu) | ((cu >> 12) & 0xf0u)) << (8 * k);
+                        }
+                        *reinterpret_cast<uint4*>(ep.pool_out + po * g.N + n) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+                        ep.pool_code[po * (g.N >> 3) + (n >> 3)] = cw;
+                        continue;
+                    }
+                    float best[8];
+                    unsigned pos[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { best[k] = -INFINITY; pos[k] = 4u; }
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx) {
+                            const int row = (2 * py + dy) * 16 + 2 * px + dx;
+                            if (row_to_m(row) < 0) continue;
+                            const uint4 v = *reinterpret_cast<const uint4*>(smem + row * (BN * 2) + (((ch ^ row) & (CPR - 1)) << 4));
+                            const unsigned wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                const float f = (k & 1) ? __uint_as_float(wds[k >> 1] & 0xffff0000u) : __uint_as_float(wds[k >> 1] << 16);
+                                if (f > best[k]) { best[k] = f; pos[k] = (unsigned)(2 * dy + dx); }
+                            }
+                        }
+                    unsigned o4[4], cw = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o4[k] = (__float_as_uint(best[2 * k]) >> 16) | (__float_as_uint(best[2 * k + 1]) & 0xffff0000u);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) cw |= (best[k] > 0.f ? pos[k] : 4u) << (4 * k);
+                    *reinterpret_cast<uint4*>(ep.pool_out + po * g.N + n) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+                    ep.pool_code[po * (g.N >> 3) + (n >> 3)] = cw;
+                }
+            }
+        }
+    }
+}
+
+template <int EPI, int BM, int BN, int CT, int PT, int NT, typename RowMap, typename PoolMap>
+__device__ __forceinline__ void staged_epilogue(f32x4_t (&acc)[CT][PT], char* smem, const ConvGeom& g, const Epilogue& ep,
+                                                int n0, int wrow0, int wcol0, int tid, RowMap row_to_m, PoolMap pool_index) {
+    constexpr int CPR = BN / 8;                 // 16-byte chunks per tile row
+    const int lane = tid & 63;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int col = wcol0 + c * 16 + (lane >> 4) * 4;
+        const int n = n0 + col;
+        float b4[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (EPI != EPI_DGRAD) { if (n < g.N) load_bias4(ep, n, g.N, n + 3 < g.N, b4); }
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            const int row = wrow0 + p * 16 + (lane & 15);
+            float v[4] = {acc[c][p][0] + b4[0], acc[c][p][1] + b4[1], acc[c][p][2] + b4[2], acc[c][p][3] + b4[3]};
+            if constexpr (EPI == EPI_FWD) {
+                if (ep.relu) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                }
+            }
+            *reinterpret_cast<uint2*>(smem + row * (BN * 2) + ((((col >> 3) ^ row) & (CPR - 1)) << 4) + (col & 4) * 2) =
+                make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+        }
+    }
+    __syncthreads();
+    staged_store<EPI, BM, BN, NT>(smem, g, ep, n0, tid, row_to_m, pool_index);
+}
+
+// callers without a pooling stage
+template <int EPI, int BM, int BN, int CT, int PT, int NT, typename RowMap>
+__device__ __forceinline__ void staged_epilogue(f32x4_t (&acc)[CT][PT], char* smem, const ConvGeom& g, const Epilogue& ep,
+                                                int n0, int wrow0, int wcol0, int tid, RowMap row_to_m) {
+    staged_epilogue<EPI, BM, BN, CT, PT, NT>(acc, smem, g, ep, n0, wrow0, wcol0, tid, row_to_m, NoPool{});
+}
+
+// Kernels that need more than 64 KB of dynamic LDS are registered once per device (idempotent; a racing second thread
+// repeats the same call).  No other process-wide state exists in this library.
+struct OnceLds { std::atomic<unsigned> done{0}; };
+inline int ensure_lds(OnceLds& o, const void* fn, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    const unsigned bit = 1u << (dev & 31);
+    if (o.done.load(std::memory_order_acquire) & bit) return 0;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return -1;
+    o.done.fetch_or(bit, std::memory_order_release);
+    return 0;
+}
+
+inline ConvGeom make_geom(int B, int H, int W, int C, int Ho, int Wo, int N, int KH, int KW, int mul, int div, int pad_t,
+                   int pad_l) {
+    ConvGeom g;
+    g.B = B; g.H = H; g.W = W; g.C = C; g.Ho = Ho; g.Wo = Wo; g.N = N; g.KH = KH; g.KW = KW;
+    g.mul = mul; g.div = div; g.pad_t = pad_t; g.pad_l = pad_l;
+    g.M = B * Ho * Wo;
+    g.nchunks = KH * KW * C / 8;
+    g.ldw = KH * KW * C;
+    g.cpt = C / 8;
+    g.d_hw = make_fastdiv(Ho * Wo);
+    g.d_w = make_fastdiv(Wo);
+    g.d_h1 = make_fastdiv(H + 1);
+    g.ablate = ssd_knob("SSD_ABLATE", 0);
+    g.s2 = 0;
+    const int s2on = ssd_knob("SSD_DGRAD_S2", 1);
+    if (div == 2 && s2on && g.cpt % 8 == 0) {
+        g.s2 = 1;
+        for (int p = 0; p < 2; ++p) { g.cls_h[p] = (Ho + 1 - p) / 2; g.cls_w[p] = (Wo + 1 - p) / 2; }
+        for (int c = 0; c < 4; ++c) g.cls_n[c] = B * g.cls_h[c >> 1] * g.cls_w[c & 1];
+    }
+    return g;
+}
+
+}  // namespace

@@ -770,6 +770,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_patch(const bf16_raw* __restric
 //   * 80 KB of LDS (two patch buffers, two weight buffers) and <= 128 VGPRs: two workgroups per CU cover each other's
 //     prologue, barriers and store tail; the next chunk's patch is prefetched at the first tap of the current one and
 //     left in flight across the barrier (counted vmcnt).
+// LDS fragment read that carries an alias scope (see lds_read_tr16_scoped): keeps the compiler's waitcnt pass from ordering
+// it behind LDS-DMA requests that are in flight for OTHER buffers.
+__device__ __forceinline__ bf16x8_t lds_read_b128_scoped(const char* __restrict__ p, const char* __restrict__ other) {
+    (void)other;
+    return *reinterpret_cast<const bf16x8_t*>(p);
+}
 constexpr int P32_PITCH = 96;
 constexpr int P32_PATCH = 32 * 1024;                       // 324 px x 96 B = 31104 B, rounded to 32 DMA instructions
 
@@ -947,6 +953,220 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
     }
     conv_epilogue_rows<EPI, CT, PT>(acc, g, ep, mrow, n0 + wave_n * (16 * CT), lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Third form of the LDS-patch kernel: 512 pixels x 128 channels per workgroup, ONE workgroup per CU (an alternative to
+// k_conv3x3_patch32<128>, bit-identical results: same chunk / tap accumulation order).
+// Twice the pixels per weight slice: 113 KB from L2 per 1152 MFMAs instead of 93 KB per 576, and a wave's tile is
+// 128 px x 64 channels (12 fragment reads per 32 MFMAs instead of 8 per 16).  With a single workgroup on the CU nobody
+// covers a stall, so latency is taken out of the loop instead:
+//   * weight slices live in a ring of FOUR tap slots: the slice of step s + 3 is requested at step s and made visible
+//     (vmcnt + barrier) at the top of step s + 2;
+//   * the next chunk's halo patch is requested in the first four taps of the current chunk (two DMA instructions per wave
+//     and tap) and is first read at the last tap;
+//   * vmcnt is counted per tap (the tap loop is unrolled and the number of DMA instructions a wave issues per tap is fixed:
+//     table N(T) below), so no wait includes a younger request;
+//   * step s runs on fragments that were read from LDS during step s - 1 (second register set), so its MFMAs start right
+//     after the barrier.
+// Measured: within +-10 % of k_conv3x3_patch32 layer by layer (faster on the deep narrow maps,
+// slower at 150x150) -- with either kernel the matrix pipes are busy ~60 % of the time and the waves are parked at the
+// per-tap wait / barrier for most of the rest.
+constexpr int P5_PIX = 34 * PATCH_W;                        // 612 halo pixels of a 32 x 16 block
+constexpr int P5_NDMA = (P5_PIX * 6 + 63) / 64;             // 58 one-KiB DMA instructions
+constexpr int P5_PATCH = P5_NDMA * 1024;                    // 59392 B per buffer
+constexpr int P5_WSLOT = 128 * 64;                          // weight slice of one tap: [128 co][32 k]
+constexpr int P5_OFF_W = 2 * P5_PATCH;
+constexpr int P5_OFF_DUMMY = P5_OFF_W + 4 * P5_WSLOT;       // landing zone of the DMA instructions beyond the patch
+constexpr int P5_LDS = P5_OFF_DUMMY + 1024;
+
+template <int EPI, bool FLAT>
+__global__ __launch_bounds__(512) void k_conv3x3_p512(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ w, ConvGeom g,
+                                                      Epilogue ep, int tiles_x, int tiles_y, int nblocks, int rowflat) {
+    constexpr int BN = 128, CT = 4, PT = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave & 3, wave_n = wave >> 2;        // pixel rows 8 wave_m .. +7 of the block, channels 64 wave_n .. +63
+    const int ntn = (g.N + BN - 1) / BN;
+    const int kx = blockIdx.x >> 3;
+    const int pblock = (kx / ntn) * 8 + (blockIdx.x & 7);   // channel tiles of one pixel block consecutive on ONE XCD
+    if (pblock >= nblocks) return;
+    const int n0 = (kx % ntn) * BN;
+    const int Q = FLAT ? g.W + 2 : PATCH_W;
+    const int img = (g.H + 1) * Q;
+    int b = 0, y0 = 0, x0 = 0, f0 = 0;
+    if constexpr (FLAT) {
+        f0 = pblock * 512;
+    } else {
+        int t = pblock;
+        const int tx = t % tiles_x; t /= tiles_x;
+        x0 = tx * 16;
+        if (rowflat) { y0 = t * 32; }
+        else { const int ty = t % tiles_y; b = t / tiles_y; y0 = ty * 32; }
+    }
+    auto image_row = [&](int r) {                           // block row (-1 .. 32) -> row of [B * H] or -1, as in k_conv3x3_patch32
+        if (!rowflat) { const int y = y0 + r; return (unsigned)y < (unsigned)g.H ? b * g.H + y : -1; }
+        const int R = y0 + r;
+        if (R < 0) return -1;
+        const int bb = fdiv(R, g.d_h1), yy = R - bb * (g.H + 1);
+        return (bb < g.B && yy < g.H) ? bb * g.H + yy : -1;
+    };
+    auto flat_pixel = [&](int f) {
+        if (f < 0) return -1;
+        const int bb = f / img;
+        const int r = f - bb * img;
+        const int yy = r / Q, xx = r - yy * Q - 1;
+        return (bb < g.B && yy < g.H && (unsigned)xx < (unsigned)g.W) ? (bb * g.H + yy) * g.W + xx : -1;
+    };
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (unsigned)g.B * g.H * g.W * g.C * 2u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (unsigned)g.N * (unsigned)g.ldw * 2u, 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;
+    // patch DMA: instruction i = wave + 8 j (j < 8; i >= 58 lands in the dummy zone) fills slots 64 i ..: slot q -> pixel q / 6,
+    // 16-byte piece q % 6 (pieces 4, 5 are the row padding)
+    unsigned pvo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int q = (wave + 8 * j) * 64 + lane;
+        const int pp = q / 6, sl = q - pp * 6;
+        int pix;
+        if constexpr (FLAT) {
+            pix = pp < 512 + 2 * (Q + 1) ? flat_pixel(f0 - (Q + 1) + pp) : -1;
+        } else {
+            const int py = pp / PATCH_W, px = pp - py * PATCH_W;
+            const int ix = x0 - 1 + px;
+            const int ir = pp < P5_PIX ? image_row(py - 1) : -1;
+            pix = (ir >= 0 && (unsigned)ix < (unsigned)g.W) ? ir * g.W + ix : -1;
+        }
+        pvo[j] = (sl < 4 && pix >= 0 && wave + 8 * j < P5_NDMA) ? ((unsigned)pix * (unsigned)g.C + (unsigned)(sl * 8)) * 2u : OOB;
+    }
+    unsigned wvo;                                           // weight DMA: wave i fills rows 16 i .. 16 i + 15 of a slot
+    {
+        const int row = 16 * wave + (lane >> 2);
+        const int piece = (lane & 3) ^ ((-(row >> 2)) & 3);
+        const int n = n0 + row;
+        wvo = n < g.N ? ((unsigned)n * (unsigned)g.ldw + (unsigned)(piece * 8)) * 2u : OOB;
+    }
+    const int nchunk = g.C >> 5;
+    const int nstep = nchunk * 9;
+    auto dma_piece = [&](int chunk, int buf, int j, bool live) {
+        char* dst = wave + 8 * j < P5_NDMA ? smem + buf * P5_PATCH + (wave + 8 * j) * 1024 : smem + P5_OFF_DUMMY;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)dst, 16, live ? pvo[j] : OOB, chunk * 64, 0, 0);
+    };
+    auto dma_w = [&](int step) {                            // slice of step (chunk = step / 9, tap = step % 9) into ring slot step & 3
+        const int st = step < nstep ? step : nstep - 1;     // past the end: a harmless refetch (the count per tap stays fixed)
+        const int ch = st / 9, tp = st - ch * 9;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_void*)(smem + P5_OFF_W + (step & 3) * P5_WSLOT + wave * 1024), 16, wvo,
+                                                 (tp * g.C + ch * 32) * 2, 0, 0);
+    };
+    f32x4_t acc[CT][PT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int p = 0; p < PT; ++p) acc[c][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fk = lane >> 4;
+    const int xbase = (FLAT ? 8 * wave_m * 16 + frow : 8 * wave_m * PATCH_W + frow) * P32_PITCH + fk * 16;
+    constexpr int prow = (FLAT ? 16 : PATCH_W) * P32_PITCH;
+    int wbase;
+    {
+        const int row = wave_n * 64 + frow;
+        wbase = P5_OFF_W + row * 64 + ((fk ^ ((-(row >> 2)) & 3)) << 4);
+    }
+    auto ldf = [&](int addr) { return lds_read_b128_scoped(smem + addr, smem); };
+    auto load_x = [&](bf16x8_t (&fx)[PT], int pb, int tap) {
+        const int tapoff = pb + xbase + ((tap / 3) * Q + tap % 3) * P32_PITCH;
+#pragma unroll
+        for (int p = 0; p < PT; ++p) fx[p] = ldf(tapoff + p * prow);
+    };
+    auto load_w = [&](bf16x8_t (&fw)[CT], int step) {
+        const int wb = (step & 3) * P5_WSLOT;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) fw[c] = ldf(wb + wbase + c * 1024);
+    };
+    // prologue: the whole first patch and the first three weight slices; fragments of step 0
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dma_piece(0, 0, j, true);
+    dma_w(0); dma_w(1); dma_w(2);
+    bf16x8_t fxa[PT], fxb[PT], fwa[CT], fwb[CT];
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");         // patch 0 and slice 0 (slices 1, 2 are younger)
+    __builtin_amdgcn_s_barrier();
+    load_x(fxa, 0, 0);
+    load_w(fwa, 0);
+    // nine taps per chunk: the register set of a step follows the parity of the GLOBAL step, so chunks go in pairs (C % 64 == 0)
+    auto run_chunk = [&](int chunk, auto par_tag) {
+        constexpr int PAR = decltype(par_tag)::value;
+        const int pb = (chunk & 1) * P5_PATCH;
+        const bool next_chunk = chunk + 1 < nchunk;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            // Step s runs on fragments read during step s - 1; at its top it makes slice s + 1 (and, at tap 8, the next patch)
+            // visible, requests slice s + 3 and two patch pieces (taps 0-3), and reads the fragments of step s + 1 under its
+            // own MFMAs.  DMA instructions a wave has issued AFTER slice s + 1 (requested two steps ago, first of its step):
+            //   T:    0  1  2  3  4  5  6  7  8
+            //   N(T): 1  3  5  5  5  3  1  1  1       (first chunk: the prologue issued patch, slices 0, 1, 2 in that order: same)
+            // All patch pieces of the NEXT chunk are requested by tap 3, i.e. older than everything tap 8 leaves in flight.
+            constexpr int NT[9] = {1, 3, 5, 5, 5, 3, 1, 1, 1};
+            if (NT[tap] == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+            else if (NT[tap] == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int step = chunk * 9 + tap;
+            dma_w(step + 3);
+            if (tap < 4) {
+                dma_piece(chunk + 1, (chunk + 1) & 1, 2 * tap, next_chunk);
+                dma_piece(chunk + 1, (chunk + 1) & 1, 2 * tap + 1, next_chunk);
+            }
+            bf16x8_t (&fxc)[PT] = ((tap + PAR) & 1) ? fxb : fxa;
+            bf16x8_t (&fxn)[PT] = ((tap + PAR) & 1) ? fxa : fxb;
+            bf16x8_t (&fwc)[CT] = ((tap + PAR) & 1) ? fwb : fwa;
+            bf16x8_t (&fwn)[CT] = ((tap + PAR) & 1) ? fwa : fwb;
+            // fragments of the next step (tap 8: tap 0 of the next chunk, from the other patch buffer; the very last step
+            // re-reads its own)
+            if (tap < 8) load_x(fxn, pb, tap + 1);
+            else load_x(fxn, next_chunk ? (P5_PATCH - pb) : pb, next_chunk ? 0 : 8);
+            load_w(fwn, step + 1 < nstep ? step + 1 : step);
+            // keep the order: the scheduler otherwise sinks these reads to just before their first use in the NEXT step
+            // (shorter live ranges) and the MFMAs of every step start by waiting for LDS
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int p = 0; p < PT; ++p)
+                    acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwc[c], fxc[p], acc[c][p], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    for (int chunk = 0; chunk < nchunk; chunk += 2) {
+        run_chunk(chunk, std::integral_constant<int, 0>{});
+        run_chunk(chunk + 1, std::integral_constant<int, 1>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the refetches past the end have landed before LDS is reused
+    if (staged_ok<EPI>(g, ep)) {                             // tile image [512 block pixels][128] over the patch buffers + ring
+        auto row_to_m = [&](int row) {
+            if constexpr (FLAT) return flat_pixel(f0 + row);
+            const int ir = image_row(row >> 4), xx = x0 + (row & 15);
+            return (ir >= 0 && xx < g.Wo) ? ir * g.Wo + xx : -1;
+        };
+        auto pool_index = [&](int py, int px) -> long long {
+            if (FLAT || rowflat) return -1;
+            const int gy = (y0 >> 1) + py, gx = (x0 >> 1) + px;
+            return (gy < ep.pool_h && gx < ep.pool_w) ? ((long long)b * ep.pool_h + gy) * ep.pool_w + gx : -1;
+        };
+        staged_epilogue<EPI, 512, BN, CT, PT, 512>(acc, smem, g, ep, n0, wave_m * 128, wave_n * 64, tid, row_to_m, pool_index);
+        return;
+    }
+    int mrow[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        if constexpr (FLAT) {
+            mrow[p] = flat_pixel(f0 + (8 * wave_m + p) * 16 + (lane & 15));
+        } else {
+            const int ir = image_row(8 * wave_m + p), xx = x0 + (lane & 15);
+            mrow[p] = (ir >= 0 && xx < g.Wo) ? ir * g.Wo + xx : -1;
+        }
+    }
+    conv_epilogue_rows<EPI, CT, PT>(acc, g, ep, mrow, n0 + wave_n * 64, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2671,7 +2891,8 @@ Knob g_knobs[] = {{"SSD_ABLATE", {KNOB_UNSET}}, {"SSD_DGRAD_S2", {KNOB_UNSET}}, 
                   {"SSD_WGRAD_PATCH_SHAPE", {KNOB_UNSET}}, {"SSD_WGRAD_TILE", {KNOB_UNSET}}, {"SSD_CONV_PATCH_FORM", {KNOB_UNSET}},
                   {"SSD_CONV_PATCH_FLAT", {KNOB_UNSET}}, {"SSD_WGRAD_FIRST", {KNOB_UNSET}}, {"SSD_CONV_FIRST", {KNOB_UNSET}},
                   {"SSD_WGRAD_PATCH_XCD", {KNOB_UNSET}}, {"SSD_CONV_C64", {KNOB_UNSET}}, {"SSD_CONV_POOL_FUSE", {KNOB_UNSET}},
-                  {"SSD_CONV_PATCH_ROWFLAT", {KNOB_UNSET}}, {"SSD_CONV_PW", {KNOB_UNSET}}, {"SSD_MATCH_FUSED", {KNOB_UNSET}}};
+                  {"SSD_CONV_PATCH_ROWFLAT", {KNOB_UNSET}}, {"SSD_CONV_PW", {KNOB_UNSET}}, {"SSD_MATCH_FUSED", {KNOB_UNSET}}, {"SSD_CONV_P512", {KNOB_UNSET}},
+                  {"SSD_CONV_PATCH_SPLIT", {KNOB_UNSET}}};
 Knob* find_knob(const char* name) {
     for (Knob& k : g_knobs) if (!strcmp(k.name, name)) return &k;
     return nullptr;
@@ -2759,6 +2980,26 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
             } while (0)
             const bool can_pool = pooled && ep.pool_out && !flat && (g.N & 7) == 0 && (ep.ldo & 7) == 0 && !(g.ablate & 8);
             if (EPI == EPI_FWD && !ep.out && !can_pool) return SSD_ERR_VALUE;
+            if (knob("SSD_CONV_P512", 0) && g.N % 128 == 0 && g.C % 64 == 0) {      // 512 px x 128 channels, one workgroup per CU
+                const int ty32 = (g.Ho + 31) / 32;
+                const unsigned strips32 = (unsigned)(((long long)g.B * (g.H + 1) + 31) / 32);
+                const int rf = (!flat && !ep.pool_out && knob("SSD_CONV_PATCH_ROWFLAT", 1) && strips32 < (unsigned)(ty32 * g.B)) ? 1 : 0;
+                const unsigned nb = flat ? (unsigned)(((long long)g.B * (g.H + 1) * (g.W + 2) + 511) / 512)
+                                         : (rf ? strips32 * (unsigned)tiles_x : (unsigned)(tiles_x * ty32 * g.B));
+                const unsigned ntn5 = (unsigned)(g.N / 128);
+                SSD_PLAN(SSD_PLAN_P512 | (flat ? SSD_PLAN_F_FLAT : 0) | (rf ? SSD_PLAN_F_ROWFLAT : 0) | (can_pool ? SSD_PLAN_F_POOL_FUSED : 0));
+                if (flat) {
+                    auto kern5 = k_conv3x3_p512<EPI, true>;
+                    static OnceLds set5; if (ensure_lds(set5, reinterpret_cast<const void*>(kern5), P5_LDS) != 0) return SSD_ERR_LAUNCH;
+                    hipLaunchKernelGGL(kern5, dim3(8 * ntn5 * ((nb + 7) / 8)), dim3(512), P5_LDS, s, xp, wp, g, ep, tiles_x, ty32, (int)nb, rf);
+                } else {
+                    auto kern5 = k_conv3x3_p512<EPI, false>;
+                    static OnceLds set5; if (ensure_lds(set5, reinterpret_cast<const void*>(kern5), P5_LDS) != 0) return SSD_ERR_LAUNCH;
+                    hipLaunchKernelGGL(kern5, dim3(8 * ntn5 * ((nb + 7) / 8)), dim3(512), P5_LDS, s, xp, wp, g, ep, tiles_x, ty32, (int)nb, rf);
+                }
+                if (can_pool) *pooled = true;
+                return ssd_launch_status();
+            }
             if (g.N <= 64) { if (flat) SSD_LAUNCH_P32(64, true); else SSD_LAUNCH_P32(64, false); }
             else { if (flat) SSD_LAUNCH_P32(128, true); else SSD_LAUNCH_P32(128, false); }
 #undef SSD_LAUNCH_P32
@@ -3303,6 +3544,7 @@ const char* ssd_conv_plan_name(int plan) {
         case SSD_PLAN_C64: return "k_conv3x3_c64";
         case SSD_PLAN_P32_64: return "k_conv3x3_patch32<64>";
         case SSD_PLAN_P32_128: return "k_conv3x3_patch32<128>";
+        case SSD_PLAN_P512: return "k_conv3x3_p512";
         case SSD_PLAN_PATCH_64: return "k_conv3x3_patch<64>";
         case SSD_PLAN_PATCH_128: return "k_conv3x3_patch<128>";
         case SSD_PLAN_8PH: return "k_conv_igemm_8ph";

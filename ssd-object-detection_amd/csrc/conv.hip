@@ -1046,6 +1046,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_p512(const bf16_raw* __restrict
         const int piece = (lane & 3) ^ ((-(row >> 2)) & 3);
         const int n = n0 + row;
         wvo = n < g.N ? ((unsigned)n * (unsigned)g.ldw + (unsigned)(piece * 8)) * 2u : OOB;
+        if (g.ablate & 16) wvo = OOB;                       // dev: weight requests fetch nothing (same instruction count)
     }
     const int nchunk = g.C >> 5;
     const int nstep = nchunk * 9;
@@ -1097,7 +1098,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_p512(const bf16_raw* __restrict
     auto run_chunk = [&](int chunk, auto par_tag) {
         constexpr int PAR = decltype(par_tag)::value;
         const int pb = (chunk & 1) * P5_PATCH;
-        const bool next_chunk = chunk + 1 < nchunk;
+        const bool next_chunk = chunk + 1 < nchunk && !(g.ablate & 32);   // dev 32: patch requests after the first fetch nothing
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             // Step s runs on fragments read during step s - 1; at its top it makes slice s + 1 (and, at tap 8, the next patch)
@@ -1126,14 +1127,20 @@ __global__ __launch_bounds__(512) void k_conv3x3_p512(const bf16_raw* __restrict
             if (tap < 8) load_x(fxn, pb, tap + 1);
             else load_x(fxn, next_chunk ? (P5_PATCH - pb) : pb, next_chunk ? 0 : 8);
             load_w(fwn, step + 1 < nstep ? step + 1 : step);
-            // keep the order: the scheduler otherwise sinks these reads to just before their first use in the NEXT step
-            // (shorter live ranges) and the MFMAs of every step start by waiting for LDS
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < CT; ++c)
 #pragma unroll
                 for (int p = 0; p < PT; ++p)
                     acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwc[c], fxc[p], acc[c][p], 0, 0, 0);
+            // Issue order inside the step: one fragment read after every two MFMAs, the last eight MFMAs without.  Left alone the scheduler either
+            // sinks the reads to just before their first use in the NEXT step (the MFMAs then start by waiting for LDS), or,
+            // pinned in front of the MFMAs, all eight waves burst 96 KB of reads at the LDS right after the barrier and the
+            // in-order MFMAs queue behind them: measured 0.59 MFMA-busy at 2.3 GHz with or without any memory traffic.
+#define SSD_P5_GROUP(NM_) __builtin_amdgcn_sched_group_barrier(0x008, NM_, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0)
+            SSD_P5_GROUP(2); SSD_P5_GROUP(2); SSD_P5_GROUP(2); SSD_P5_GROUP(2); SSD_P5_GROUP(2); SSD_P5_GROUP(2);
+            SSD_P5_GROUP(2); SSD_P5_GROUP(2); SSD_P5_GROUP(2); SSD_P5_GROUP(2); SSD_P5_GROUP(2); SSD_P5_GROUP(2);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // the last eight MFMAs cover the latency of the last reads
+#undef SSD_P5_GROUP
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -2980,13 +2987,16 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
             } while (0)
             const bool can_pool = pooled && ep.pool_out && !flat && (g.N & 7) == 0 && (ep.ldo & 7) == 0 && !(g.ablate & 8);
             if (EPI == EPI_FWD && !ep.out && !can_pool) return SSD_ERR_VALUE;
-            if (knob("SSD_CONV_P512", 0) && g.N % 128 == 0 && g.C % 64 == 0) {      // 512 px x 128 channels, one workgroup per CU
+            // 512 px x 128 channels, one workgroup per CU: from 256 input channels on (eight 32-channel chunks amortise its longer
+            // prologue / epilogue; measured per layer in DESIGN.md section 9).  SSD_CONV_P512: 0 never, 1 (default) that rule, 2 always
+            const int p512 = knob("SSD_CONV_P512", 1);
+            if (p512 && g.C % 64 == 0 && g.N > 64 && (p512 >= 2 || g.C >= 256)) {
                 const int ty32 = (g.Ho + 31) / 32;
                 const unsigned strips32 = (unsigned)(((long long)g.B * (g.H + 1) + 31) / 32);
                 const int rf = (!flat && !ep.pool_out && knob("SSD_CONV_PATCH_ROWFLAT", 1) && strips32 < (unsigned)(ty32 * g.B)) ? 1 : 0;
                 const unsigned nb = flat ? (unsigned)(((long long)g.B * (g.H + 1) * (g.W + 2) + 511) / 512)
                                          : (rf ? strips32 * (unsigned)tiles_x : (unsigned)(tiles_x * ty32 * g.B));
-                const unsigned ntn5 = (unsigned)(g.N / 128);
+                const unsigned ntn5 = (unsigned)((g.N + 127) / 128);
                 SSD_PLAN(SSD_PLAN_P512 | (flat ? SSD_PLAN_F_FLAT : 0) | (rf ? SSD_PLAN_F_ROWFLAT : 0) | (can_pool ? SSD_PLAN_F_POOL_FUSED : 0));
                 if (flat) {
                     auto kern5 = k_conv3x3_p512<EPI, true>;

@@ -38,7 +38,7 @@ def plan_names(case):
             plan_name(L, L.ssd_conv2d_bwd_weight_plan(B, H, W, Cin, Cout, cp, k, stride, pt, pl, Ho, Wo)))
 
 
-P32_64, P32_128 = "k_conv3x3_patch32<64>", "k_conv3x3_patch32<128>"
+P32_64, P32_128, P512 = "k_conv3x3_patch32<64>", "k_conv3x3_patch32<128>", "k_conv3x3_p512"
 DMA = "k_conv_igemm_dma<%s>"
 WP16, WP6, WP10 = "k_conv3x3_wgrad_patch<16,2>", "k_conv3x3_wgrad_patch<6,5>", "k_conv3x3_wgrad_patch<10,3>"
 
@@ -63,9 +63,12 @@ CASES = [
     (3, 19, 19, 256, 320, 1, 1, "same", (DMA % "128,128", DMA % "128,128", "k_conv_wgrad")),                  # pointwise, ragged channel tile (M = 1083: below the 256x256 wgrad GEMM)
     (2, 21, 21, 64, 264, 3, 2, "same", (DMA % "128,128" + "+splitk", DMA % "128,64" + "+splitk", "k_conv_wgrad")),  # strided 3x3, 264 filters
     (2, 38, 38, 64, 192, 3, 1, "same", (P32_128 + "+flat", P32_64 + "+rowflat", WP6)),                        # strip blocks (narrow map, N > 128)
-    (3, 19, 19, 128, 320, 3, 1, "same", (P32_128 + "+flat", P32_128 + "+rowflat", WP10)),                     # strip blocks spanning images, two chunks x three channel tiles
+    (3, 19, 19, 128, 320, 3, 1, "same", (P32_128 + "+flat", P512 + "+rowflat", WP10)),                        # strip blocks spanning images, two chunks x three channel tiles; data gradient (320 in-channels) on the 512-pixel kernel with a ragged last chunk pair
     (5, 70, 45, 64, 64, 3, 1, "same", ("k_conv3x3_c64b", "k_conv3x3_c64b", WP10 + "+rwide")),                 # 64 -> 64 persistent kernel, ragged blocks; >= 32 wgrad splits
     (8, 48, 48, 64, 128, 3, 1, "same", (P32_128, P32_64, WP16 + "+rwide")),                                   # 16x16 wgrad blocks with >= 32 splits (the wide reduction, as block1-3)
+    (2, 33, 18, 256, 128, 3, 1, "same", (P512 + "+rowflat", P32_128 + "+flat", WP10)),                        # 512-pixel kernel (>= 256 in-channels): 32-row strip blocks over two images, partial in both dims
+    (3, 19, 19, 256, 256, 3, 1, "same", (P512 + "+flat", P512 + "+flat", WP10)),                              # 512-pixel kernel, strip-of-positions blocks spanning images, forward and data gradient
+    (2, 40, 40, 256, 128, 3, 1, "same", (P512 + "+rowflat", DMA % "128,128" + "+splitk", WP6)),               # 512-pixel kernel, three column tiles, last one partial
 ]
 
 # Shapes that reach the large-problem kernels; the first five and the last four are layers of the batch-64 SSD300 step.
@@ -74,7 +77,7 @@ FULL_SIZE_CASES = [
     (64, 19, 19, 1024, 1024, 1, 1, "same", ("k_conv_igemm_8ph", "k_conv_igemm_8ph", "k_conv_wgrad_tile")),              # conv14 (1x1 at 19x19)
     (64, 38, 38, 512, 1024, 3, 2, "same", ("k_conv_igemm_8ph", DMA % "256,256" + "+s2", "k_conv_wgrad_tile")),          # conv13 (3x3 stride 2, 38 -> 19)
     (64, 19, 19, 1024, 256, 1, 1, "same", (DMA % "128,128", "k_conv_igemm_8ph", "k_conv_wgrad_tile+rwide")),            # conv15
-    (64, 38, 38, 512, 340, 3, 1, "same", (P32_128 + "+flat", "k_conv_igemm_8ph", WP6)),                                 # head 0 (data gradient from 344 padded channels)
+    (64, 38, 38, 512, 340, 3, 1, "same", (P512 + "+flat", "k_conv_igemm_8ph", WP6)),                                    # head 0 (data gradient from 344 padded channels)
     (8, 64, 64, 64, 320, 1, 1, "same", (DMA % "256,128", DMA % "128,64", "k_conv_wgrad+rwide")),                        # 256x128 tiles (N = 320 pads badly to 512)
     (6, 128, 128, 128, 64, 1, 1, "same", (DMA % "256,64", DMA % "256,128", "k_conv_wgrad+rwide")),                      # 256x64 tiles
     (11, 64, 64, 32, 512, 1, 1, "same", (DMA % "256,256", DMA % "128,64", "k_conv_wgrad+rwide")),                       # 256x256 LDS-DMA tiles without the 8-phase pipeline (Cin < 64)

@@ -250,13 +250,14 @@ def test_wgrad_padded_dy(ops):
     assert (db.cpu() - dy[..., :Cout].float().sum((0, 1, 2))).abs().max().item() <= 1e-3 * 30
 
 
-def test_head_fwd_layout(ops):
+@pytest.mark.parametrize("shape", [(2, 5, 5, 64, 6), (2, 19, 19, 256, 4)])     # generic GEMM; k_conv3x3_p512 strip blocks (as head 0 / 1)
+def test_head_fwd_layout(ops, shape):
     """Fused loc+conf head writes the reference's Reshape/Concatenate layout (models/ssd_model.py:166-167)."""
-    B, H, W, Cin, n, C = 2, 5, 5, 64, 6, 81
+    (B, H, W, Cin, n), C = shape, 81
     A, off = 200 + H * W * n, 200
     g = torch.Generator().manual_seed(9)
     x = torch.randn((B, H, W, Cin), generator=g).bfloat16()
-    w = (torch.randn((n * (4 + C), 3, 3, Cin), generator=g) / 24).bfloat16()
+    w = (torch.randn((n * (4 + C), 3, 3, Cin), generator=g) / np.sqrt(9 * Cin)).bfloat16()
     bias = torch.randn((n * (4 + C),), generator=g) * 0.1
     loc = torch.zeros((B, A, 4), dtype=torch.bfloat16, device="cuda")
     conf = torch.zeros((B, A, C), dtype=torch.bfloat16, device="cuda")
@@ -305,7 +306,8 @@ def test_maxpool(ops, H, same):
     assert torch.equal(dx2, dx)
 
 
-@pytest.mark.parametrize("case", [(2, 46, 64, 64, False), (2, 75, 128, 256, True), (1, 33, 64, 96, True), (2, 19, 128, 128, False)])
+@pytest.mark.parametrize("case", [(2, 46, 64, 64, False), (2, 75, 128, 256, True), (1, 33, 64, 96, True), (2, 19, 128, 128, False),
+                                  (2, 40, 256, 128, True), (1, 75, 256, 256, True)])      # the last two: k_conv3x3_p512's pooling epilogue
 def test_conv_fwd_pool_fused(ops, case):
     """conv + ReLU + 2x2 pooling in one call == the separate calls, bit for bit (the fused form pools the tile the
     convolution kernel holds on chip; layers without a 16x16-block kernel fall back to two launches)."""

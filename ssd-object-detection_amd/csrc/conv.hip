@@ -2898,8 +2898,7 @@ Knob g_knobs[] = {{"SSD_ABLATE", {KNOB_UNSET}}, {"SSD_DGRAD_S2", {KNOB_UNSET}}, 
                   {"SSD_WGRAD_PATCH_SHAPE", {KNOB_UNSET}}, {"SSD_WGRAD_TILE", {KNOB_UNSET}}, {"SSD_CONV_PATCH_FORM", {KNOB_UNSET}},
                   {"SSD_CONV_PATCH_FLAT", {KNOB_UNSET}}, {"SSD_WGRAD_FIRST", {KNOB_UNSET}}, {"SSD_CONV_FIRST", {KNOB_UNSET}},
                   {"SSD_WGRAD_PATCH_XCD", {KNOB_UNSET}}, {"SSD_CONV_C64", {KNOB_UNSET}}, {"SSD_CONV_POOL_FUSE", {KNOB_UNSET}},
-                  {"SSD_CONV_PATCH_ROWFLAT", {KNOB_UNSET}}, {"SSD_CONV_PW", {KNOB_UNSET}}, {"SSD_MATCH_FUSED", {KNOB_UNSET}}, {"SSD_CONV_P512", {KNOB_UNSET}},
-                  {"SSD_CONV_PATCH_SPLIT", {KNOB_UNSET}}};
+                  {"SSD_CONV_PATCH_ROWFLAT", {KNOB_UNSET}}, {"SSD_MATCH_FUSED", {KNOB_UNSET}}, {"SSD_CONV_P512", {KNOB_UNSET}}};
 Knob* find_knob(const char* name) {
     for (Knob& k : g_knobs) if (!strcmp(k.name, name)) return &k;
     return nullptr;
@@ -3566,7 +3565,6 @@ const char* ssd_conv_plan_name(int plan) {
         case SSD_PLAN_REG_64: return "k_conv_igemm<64>";
         case SSD_PLAN_REG_128: return "k_conv_igemm<128>";
         case SSD_PLAN_CONV0_FWD: return "k_conv0_fwd";
-        case SSD_PLAN_PW: return "k_conv_pw";
         case SSD_PLAN_WG_FIRST: return "k_conv0_wgrad";
         case SSD_PLAN_WG_PATCH_16x16: return "k_conv3x3_wgrad_patch<16,2>";
         case SSD_PLAN_WG_PATCH_6x40: return "k_conv3x3_wgrad_patch<6,5>";

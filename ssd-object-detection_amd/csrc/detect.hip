@@ -23,36 +23,72 @@ constexpr int WG = 256;
 constexpr int ROWS = 128;
 constexpr int CAP = 1024;                    // candidates per image that can take part in NMS
 
-template <typename T>
+// CC: the class count when it is known at compile time (81: the reference's 80 classes + background), else 0.  With a fixed
+// trip count both per-row loops unroll, the 40 LDS reads of a half row are issued together and the exponentials pipeline;
+// the order of the additions (and so every bit of the result) is that of the rolled loop.
+template <typename T, int CC>
 __global__ __launch_bounds__(WG) void k_score_decode(const T* __restrict__ conf, const T* __restrict__ loc,
-                                                     const double* __restrict__ priors, size_t n, int A, int C,
+                                                     const double* __restrict__ priors, size_t n, int A, int C_rt,
                                                      float thresh, double in_size, float* __restrict__ score,
                                                      int* __restrict__ cls, float4* __restrict__ box,
                                                      uint8_t* __restrict__ cand) {
     extern __shared__ __attribute__((aligned(16))) float s_z[];
+    const int C = CC ? CC : C_rt;
     const size_t nblk = (n + ROWS - 1) / ROWS;
     const int r = threadIdx.x >> 1, half = threadIdx.x & 1;
     const int nfg = C - 1;
     const int k0 = half ? (nfg + 1) / 2 : 0, k1 = half ? nfg : (nfg + 1) / 2;
+    constexpr int FIXED = CC && ((CC - 1) % 2 == 0) ? (CC - 1) / 2 : 0;      // trip count of both halves when it is the same
+    // with a fixed class count the next block's logits are requested before the current block is scored (registers), and
+    // written to LDS after the barrier that ends it: the loads are in flight during the exponentials
+    constexpr int NV = CC ? (ROWS * CC * (int)sizeof(T) / 16 + WG - 1) / WG : 1;
+    uint4 raw[NV];
+    if constexpr (CC != 0) {
+        if (blockIdx.x < nblk) {
+            const size_t row0 = (size_t)blockIdx.x * ROWS;
+            stage_load<T, NV>(conf + row0 * C, (size_t)min((size_t)ROWS, n - row0) * C, raw);
+        }
+    }
     for (size_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         const size_t row0 = blk * ROWS;
         const int nrow = (int)min((size_t)ROWS, n - row0);
         __syncthreads();
-        stage_block<T>(conf + row0 * C, (size_t)nrow * C, s_z);
+        if constexpr (CC != 0) stage_store<T, NV>(conf + row0 * C, (size_t)nrow * C, raw, s_z);
+        else stage_block<T>(conf + row0 * C, (size_t)nrow * C, s_z);
         __syncthreads();
+        if constexpr (CC != 0) {
+            const size_t nxt = blk + gridDim.x;
+            if (nxt < nblk) {
+                const size_t r1 = nxt * ROWS;
+                stage_load<T, NV>(conf + r1 * C, (size_t)min((size_t)ROWS, n - r1) * C, raw);
+            }
+        }
         if (r < nrow) {
             const float* z = s_z + r * C;
             float m = -INFINITY;                 // best foreground logit of this half, first index wins
             int mi = INT_MAX;
-            for (int k = k0; k < k1; ++k)
-                if (z[k] > m) { m = z[k]; mi = k; }
+            if constexpr (FIXED > 0) {
+#pragma unroll
+                for (int j = 0; j < FIXED; ++j) {
+                    const int k = k0 + j;
+                    if (z[k] > m) { m = z[k]; mi = k; }
+                }
+            } else {
+                for (int k = k0; k < k1; ++k)
+                    if (z[k] > m) { m = z[k]; mi = k; }
+            }
             const float om = __shfl_xor(m, 1);
             const int oi = __shfl_xor(mi, 1);
             if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
             const float zb = z[nfg];
             const float top = fmaxf(m, zb);
             float s = 0.f;
-            for (int k = k0; k < k1; ++k) s += __expf(z[k] - top);
+            if constexpr (FIXED > 0) {
+#pragma unroll
+                for (int j = 0; j < FIXED; ++j) s += __expf(z[k0 + j] - top);
+            } else {
+                for (int k = k0; k < k1; ++k) s += __expf(z[k] - top);
+            }
             s += __shfl_xor(s, 1);
             if (half == 0) {
                 const size_t g = row0 + r;
@@ -279,13 +315,12 @@ int ssd_score_decode(const void* conf, const void* loc, int dtype, const double*
     const size_t nblk = (n + ROWS - 1) / ROWS;
     const unsigned grid = (unsigned)(nblk < 768 ? nblk : 768);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == SSD_F32)
-        hipLaunchKernelGGL(k_score_decode<float>, dim3(grid), dim3(WG), lds, s, (const float*)conf, (const float*)loc,
-                           priors, n, A, C, score_thresh, in_size, score, cls, reinterpret_cast<float4*>(box), cand);
-    else
-        hipLaunchKernelGGL(k_score_decode<__hip_bfloat16>, dim3(grid), dim3(WG), lds, s, (const __hip_bfloat16*)conf,
-                           (const __hip_bfloat16*)loc, priors, n, A, C, score_thresh, in_size, score, cls,
-                           reinterpret_cast<float4*>(box), cand);
+#define SSD_LAUNCH_SCORE(T_, CC_)                                                                                     \
+    hipLaunchKernelGGL((k_score_decode<T_, CC_>), dim3(grid), dim3(WG), lds, s, (const T_*)conf, (const T_*)loc, priors, n, A, C, \
+                       score_thresh, in_size, score, cls, reinterpret_cast<float4*>(box), cand)
+    if (dtype == SSD_F32) { if (C == 81) SSD_LAUNCH_SCORE(float, 81); else SSD_LAUNCH_SCORE(float, 0); }
+    else { if (C == 81) SSD_LAUNCH_SCORE(__hip_bfloat16, 81); else SSD_LAUNCH_SCORE(__hip_bfloat16, 0); }
+#undef SSD_LAUNCH_SCORE
     return ssd_launch_status();
 }
 

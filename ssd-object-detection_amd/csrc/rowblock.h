@@ -49,3 +49,43 @@ __device__ __forceinline__ void stage_block(const T* __restrict__ src, size_t co
     for (size_t i = nvec * PER + threadIdx.x; i < count; i += RB_WG) lds[i] = to_f32<T>(src[i]);
 }
 
+
+// The same staging split in two, for a loop that requests the NEXT block's elements (stage_load) before it computes on the
+// current one and writes them to LDS (stage_store) after the following barrier: the global loads are in flight during the
+// computation.  NV = ceil(count / (16 / sizeof(T)) / RB_WG) registers of 16 bytes per lane.
+template <typename T, int NV>
+__device__ __forceinline__ void stage_load(const T* __restrict__ src, size_t count, uint4 (&raw)[NV]) {
+    constexpr int PER = 16 / sizeof(T);
+    const size_t nvec = count / PER;
+    const uint4* v = reinterpret_cast<const uint4*>(src);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const size_t i = (size_t)j * RB_WG + threadIdx.x;
+        if (i < nvec) raw[j] = v[i];
+    }
+}
+
+template <typename T, int NV>
+__device__ __forceinline__ void stage_store(const T* __restrict__ src, size_t count, const uint4 (&raw)[NV], float* lds) {
+    constexpr int PER = 16 / sizeof(T);
+    const size_t nvec = count / PER;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const size_t i = (size_t)j * RB_WG + threadIdx.x;
+        if (i >= nvec) continue;
+        if constexpr (sizeof(T) == 4) {
+            *reinterpret_cast<uint4*>(lds + i * 4) = raw[j];
+        } else {
+            const unsigned w[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
+            float f[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                f[2 * k] = __uint_as_float(w[k] << 16);
+                f[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+            }
+            *reinterpret_cast<float4*>(lds + i * 8) = make_float4(f[0], f[1], f[2], f[3]);
+            *reinterpret_cast<float4*>(lds + i * 8 + 4) = make_float4(f[4], f[5], f[6], f[7]);
+        }
+    }
+    for (size_t i = nvec * PER + threadIdx.x; i < count; i += RB_WG) lds[i] = to_f32<T>(src[i]);   // ragged tail (last block only)
+}

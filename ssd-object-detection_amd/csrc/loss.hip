@@ -90,32 +90,64 @@ __device__ __forceinline__ double block_sum(double v, double* s_red) {
 // ------------------------------------------------------------------------------------------------
 // Pass 1: one read of conf.  Per anchor: logsumexp, both CEs; per block: partial sums, P; level-1
 // histogram of the masked background CE keys.
-template <typename T>
+// CC: the logit count when it is known at compile time (81), else 0.  Fixed count: both per-row loops unroll (the shorter half
+// row pads with max(m, -inf) / s + 0, which change no bit), the LDS reads of a half row are issued together, and the next
+// block's logits are requested before the current block is reduced (as k_score_decode).
+template <typename T, int CC>
 __global__ __launch_bounds__(WG) void k_loss_rows(const T* __restrict__ conf, const T* __restrict__ loc,
                                                   const int* __restrict__ cls, const float* __restrict__ gloc,
-                                                  const uint8_t* __restrict__ mask, size_t n, int C, LossWs w) {
+                                                  const uint8_t* __restrict__ mask, size_t n, int C_rt, LossWs w) {
     extern __shared__ __attribute__((aligned(16))) float s_z[];   // [ROWS*C]
     __shared__ int s_hist[HB1];
     __shared__ double s_red[4];
+    const int C = CC ? CC : C_rt;
     const size_t nblk = (n + ROWS - 1) / ROWS;
     for (int i = threadIdx.x; i < HB1; i += WG) s_hist[i] = 0;
     int my_pos = 0;
     const int r = threadIdx.x >> 1, half = threadIdx.x & 1;
     const int k0 = half ? (C + 1) / 2 : 0, k1 = half ? C : (C + 1) / 2;
+    constexpr int FIXED = (CC + 1) / 2;                       // trip count of the longer half row
+    constexpr int NV = CC ? (ROWS * CC * (int)sizeof(T) / 16 + WG - 1) / WG : 1;
+    uint4 raw[NV];
+    if constexpr (CC != 0) {
+        if (blockIdx.x < nblk) {
+            const size_t row0 = (size_t)blockIdx.x * ROWS;
+            stage_load<T, NV>(conf + row0 * C, (size_t)min((size_t)ROWS, n - row0) * C, raw);
+        }
+    }
     for (size_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         const size_t row0 = blk * ROWS;
         const int nrow = (int)min((size_t)ROWS, n - row0);
         __syncthreads();                                   // previous block's LDS reads are done
-        stage_block<T>(conf + row0 * C, (size_t)nrow * C, s_z);
+        if constexpr (CC != 0) stage_store<T, NV>(conf + row0 * C, (size_t)nrow * C, raw, s_z);
+        else stage_block<T>(conf + row0 * C, (size_t)nrow * C, s_z);
         __syncthreads();
+        if constexpr (CC != 0) {
+            const size_t nxt = blk + gridDim.x;
+            if (nxt < nblk) {
+                const size_t r1 = nxt * ROWS;
+                stage_load<T, NV>(conf + r1 * C, (size_t)min((size_t)ROWS, n - r1) * C, raw);
+            }
+        }
         double acc_pos = 0.0, acc_l1 = 0.0;
         if (r < nrow) {
             const float* z = s_z + r * C;
             float m = -INFINITY;
-            for (int k = k0; k < k1; ++k) m = fmaxf(m, z[k]);
-            m = fmaxf(m, __shfl_xor(m, 1));
             float s = 0.f;
-            for (int k = k0; k < k1; ++k) s += __expf(z[k] - m);
+            if constexpr (CC != 0) {
+                float zz[FIXED];
+#pragma unroll
+                for (int j = 0; j < FIXED; ++j) zz[j] = k0 + j < k1 ? z[k0 + j] : -INFINITY;
+#pragma unroll
+                for (int j = 0; j < FIXED; ++j) m = fmaxf(m, zz[j]);
+                m = fmaxf(m, __shfl_xor(m, 1));
+#pragma unroll
+                for (int j = 0; j < FIXED; ++j) s += k0 + j < k1 ? __expf(zz[j] - m) : 0.f;
+            } else {
+                for (int k = k0; k < k1; ++k) m = fmaxf(m, z[k]);
+                m = fmaxf(m, __shfl_xor(m, 1));
+                for (int k = k0; k < k1; ++k) s += __expf(z[k] - m);
+            }
             s += __shfl_xor(s, 1);
             if (half == 0) {
                 const size_t g = row0 + r;
@@ -394,8 +426,10 @@ int launch_loss(const void* conf, const void* loc, const int32_t* cls, const flo
     const size_t lds = ((size_t)ROWS * C * sizeof(float) + 15) / 16 * 16;
     if (hipMemsetAsync(w.hist1, 0, w.zero_bytes, s) != hipSuccess) return SSD_ERR_LAUNCH;
     const unsigned pgrid = (unsigned)min((size_t)MAX_PERSIST, nblk);
-    hipLaunchKernelGGL(k_loss_rows<T>, dim3(pgrid), dim3(WG), lds, s, (const T*)conf, (const T*)loc, cls, gloc,
-                       mask, n, C, w);
+    if (C == 81)
+        hipLaunchKernelGGL((k_loss_rows<T, 81>), dim3(pgrid), dim3(WG), lds, s, (const T*)conf, (const T*)loc, cls, gloc, mask, n, C, w);
+    else
+        hipLaunchKernelGGL((k_loss_rows<T, 0>), dim3(pgrid), dim3(WG), lds, s, (const T*)conf, (const T*)loc, cls, gloc, mask, n, C, w);
     hipLaunchKernelGGL(k_loss_collapse, dim3((HB1 + WG) / WG), dim3(WG), 0, s, w);
     const unsigned hgrid = (unsigned)min((size_t)256, (n + WG - 1) / WG);
     hipLaunchKernelGGL(k_loss_hist<2>, dim3(hgrid), dim3(WG), 0, s, n, w);

@@ -145,7 +145,7 @@ __device__ __forceinline__ int wg_prefix(bool flag, int* s_wave, int& total) {
 __global__ __launch_bounds__(WG) void k_nms(const float* __restrict__ score, const int* __restrict__ cls,
                                             const float4* __restrict__ box, const uint8_t* __restrict__ cand, int A,
                                             float iou_thresh, int max_cand, uint8_t* __restrict__ keep,
-                                            int* __restrict__ keep_count) {
+                                            int* __restrict__ keep_count, int ablate) {
     __shared__ unsigned long long s_key[CAP];
     __shared__ float4 s_box[CAP];
     __shared__ unsigned char s_alive[CAP];
@@ -159,15 +159,37 @@ __global__ __launch_bounds__(WG) void k_nms(const float* __restrict__ score, con
     const float* sc = score + off;
     const uint8_t* cd = cand + off;
 
-    // count candidates, clear the output row
-    int cnt = 0;
-    for (int a = tid; a < A; a += WG) {
-        keep[off + a] = 0;
-        cnt += cd[a] ? 1 : 0;
-    }
+    // clear the output row, count the candidates and -- optimistically -- compact them in the same sweep: when all of them
+    // take part (total <= max_cand, the usual case) the sort below orders them completely (the anchor index is part of the
+    // key), so their order in s_key is irrelevant: one LDS counter, no barrier between the anchor strides, every load of
+    // the sweep in flight at once.  (The ordered compaction further down -- needed only for the exact top-max_cand cut --
+    // costs two workgroup prefix sums and a global-memory round trip per stride of 256 anchors, 34 strides per image.)
     if (tid < 4) s_misc[tid] = 0;
     __syncthreads();
-    atomicAdd(&s_misc[0], cnt);
+    auto take_cand = [&](int a) {
+        const int slot = atomicAdd(&s_misc[0], 1);
+        if (slot < CAP)
+            s_key[slot] = ((unsigned long long)(unsigned)cls[off + a] << 48) |
+                          ((unsigned long long)(0xffffffffu - __float_as_uint(sc[a])) << 16) | (unsigned long long)(unsigned)a;
+    };
+    if ((A & 3) == 0) {                      // rows of cand / keep are 4-byte aligned: four anchors per load / store
+        const unsigned* cd4 = reinterpret_cast<const unsigned*>(cd);
+        unsigned* kp4 = reinterpret_cast<unsigned*>(keep + off);
+        for (int q = tid; q < (A >> 2); q += WG) {
+            kp4[q] = 0u;
+            const unsigned c4 = cd4[q];
+            if (c4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if ((c4 >> (8 * e)) & 0xffu) take_cand(4 * q + e);
+            }
+        }
+    } else {
+        for (int a = tid; a < A; a += WG) {
+            keep[off + a] = 0;
+            if (cd[a]) take_cand(a);
+        }
+    }
     __syncthreads();
     const int total = s_misc[0];
     if (total == 0) {
@@ -209,6 +231,7 @@ __global__ __launch_bounds__(WG) void k_nms(const float* __restrict__ score, con
         need_eq = k;                         // how many of the keys equal to the cut are still wanted
     }
 
+    if (total > max_cand) {
     // ordered compaction (anchor order) of the participating candidates
     int filled = 0, eq_seen = 0;
     for (int a0 = 0; a0 < A; a0 += WG) {
@@ -233,7 +256,28 @@ __global__ __launch_bounds__(WG) void k_nms(const float* __restrict__ score, con
         }
         filled += tot;
     }
-    // pad to a power of two and sort ascending: class asc, score desc, anchor asc
+    }
+    if (ablate & 1) return;
+    // sort ascending: class asc, score desc, anchor asc.  Up to 512 keys by rank (keys are unique: every thread counts the keys
+    // below its own with broadcast LDS reads and writes its key to that slot -- two barriers instead of the 45 of a 512-key
+    // bitonic network); more keys: bitonic, padded to a power of two
+    if (take <= 512) {
+        __syncthreads();
+        unsigned long long mine[2];
+        int rank[2] = {0, 0};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) mine[e] = tid + e * WG < take ? s_key[tid + e * WG] : ~0ull;
+        for (int j = 0; j < take; ++j) {
+            const unsigned long long kj = s_key[j];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) rank[e] += kj < mine[e] ? 1 : 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            if (tid + e * WG < take) s_key[rank[e]] = mine[e];
+        __syncthreads();
+    } else {
     int npow = 1;
     while (npow < take) npow <<= 1;
     for (int i = take + tid; i < npow; i += WG) s_key[i] = ~0ull;
@@ -250,6 +294,8 @@ __global__ __launch_bounds__(WG) void k_nms(const float* __restrict__ score, con
             }
             __syncthreads();
         }
+    }
+    if (ablate & 2) return;
     // gather boxes, mark class-segment starts
     for (int i = tid; i < take; i += WG) {
         const int a = (int)(s_key[i] & 0xffffull);
@@ -272,11 +318,29 @@ __global__ __launch_bounds__(WG) void k_nms(const float* __restrict__ score, con
     if (tid == 0) s_seg[nseg] = take;
     __syncthreads();
 
+    if (ablate & 4) return;
     // greedy pass: one wave per class segment
     volatile unsigned char* alive = s_alive;
     int kept = 0;
     for (int sg = wave; sg < nseg; sg += 4) {
         const int lo = s_seg[sg], hi = s_seg[sg + 1];
+        if (hi - lo <= 64) {
+            // a segment that fits a wave (nearly all do) runs in registers: lane l holds box lo + l, the alive set is a
+            // 64-bit wave-uniform mask, box i reaches the lanes by a broadcast -- no LDS round trip per kept box (the LDS
+            // form below spent ~1 us per box on its dependent reads: 35 of this kernel's 64 us)
+            const int nb = hi - lo;
+            const float4 bj = lane < nb ? s_box[lo + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+            unsigned long long am = nb == 64 ? ~0ull : ((1ull << nb) - 1ull);
+            for (int i = 0; i < nb; ++i) {
+                if (!((am >> i) & 1ull)) continue;           // wave-uniform
+                const float4 bi = make_float4(__shfl(bj.x, i), __shfl(bj.y, i), __shfl(bj.z, i), __shfl(bj.w, i));
+                const bool sup = lane > i && lane < nb && iou_f32(bi, bj) > iou_thresh;
+                am &= ~__ballot(sup);
+            }
+            if (lane < nb && ((am >> lane) & 1ull)) keep[off + (int)(s_key[lo + lane] & 0xffffull)] = 1;
+            if (lane == 0) kept += __popcll(am);
+            continue;
+        }
         for (int i = lo; i < hi; ++i) {
             if (!alive[i]) continue;             // wave-uniform
             if (lane == 0) {
@@ -331,7 +395,7 @@ int ssd_nms(const float* score, const int32_t* cls, const float* box, const uint
     if (B <= 0 || A <= 0 || A > 65536 || max_cand <= 0 || max_cand > CAP) return SSD_ERR_VALUE;
     if (!score || !cls || !box || !cand || !keep) return SSD_ERR_VALUE;
     hipLaunchKernelGGL(k_nms, dim3(B), dim3(WG), 0, (hipStream_t)stream, score, cls, reinterpret_cast<const float4*>(box),
-                       cand, A, iou_thresh, max_cand, keep, keep_count);
+                       cand, A, iou_thresh, max_cand, keep, keep_count, ssd_knob("SSD_ABLATE", 0));
     return ssd_launch_status();
 }
 

@@ -13,6 +13,12 @@ for dt in (torch.float32, torch.bfloat16):
     t_nms = bench.graph_timed(torch, lambda: ops.nms(sd[0], sd[1], sd[2], sd[3], 0.45, 400), 30)
     print(dt, "score_decode %.1f us  (%.2f us/img, %.0f GB/s)  nms %.1f us" % (t_sd * 1e6, t_sd / B * 1e6,
           conf.numel() * conf.element_size() / t_sd / 1e9, t_nms * 1e6), flush=True)
+    from ssd_object_detection_amd import _lib
+    L = _lib.lib()
+    for a in (1, 2, 4):
+        L.ssd_dev_knob(b"SSD_ABLATE", a)
+        print("   nms stop after stage %d: %.1f us" % (a, bench.graph_timed(torch, lambda: ops.nms(sd[0], sd[1], sd[2], sd[3], 0.45, 400), 30) * 1e6), flush=True)
+    L.ssd_dev_knob(b"SSD_ABLATE", 0)
     dst = torch.empty_like(conf)
     t_cp = bench.graph_timed(torch, lambda: dst.copy_(conf), 30)
     t_sum = bench.graph_timed(torch, lambda: conf.amax(dim=2), 30)

@@ -154,7 +154,8 @@ def run_rank(args):
     backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("SSD_DIST_BACKEND", "nccl")
+        # RCCL needs one GPU per rank; with fewer GPUs than ranks (a one-GPU box rehearsing the multi-rank path) fall back to gloo
+        backend = os.environ.get("SSD_DIST_BACKEND", "nccl" if torch.cuda.device_count() >= world else "gloo")
         try:                                    # bind the communicator to this rank's GPU up front (no lazy-init surprises)
             dist.init_process_group(backend, device_id=torch.device("cuda", torch.cuda.current_device())
                                     if backend == "nccl" else None)

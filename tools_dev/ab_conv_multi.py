@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import ssd_object_detection_amd.ops as ops
 from ssd_object_detection_amd import _lib
+if os.environ.get('AB_LIB'):
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ['AB_LIB'])      # dev: time another build of the library
 from tests.conv_cases import plan_name
 L = _lib.lib()
 torch.manual_seed(0)

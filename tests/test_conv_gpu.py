@@ -214,6 +214,45 @@ def test_patch_row_strip_is_bitwise_neutral(ops, case):
     assert (outs[1][0].float().cpu() - yr).abs().max().item() <= 2 ** -7 * max(1.0, yr.abs().max().item())
 
 
+# the batch-64 layers k_conv3x3_p512 serves (block3_conv2/3, block4_conv1/2 and their data gradients, head 1's data gradient
+# shape) plus one small map with partial blocks in both dimensions
+P512_LAYERS = [(64, 75, 75, 256, 256), (64, 38, 38, 256, 512), (64, 38, 38, 512, 512), (16, 19, 19, 1024, 512), (3, 33, 50, 256, 128)]
+
+
+@pytest.mark.parametrize("case", P512_LAYERS, ids=[str(c) for c in P512_LAYERS])
+def test_p512_equals_patch32_at_layer_size(ops, case):
+    """k_conv3x3_p512 and k_conv3x3_patch32 accumulate in the same order (32-channel chunks, nine taps each), so they agree bit
+    for bit: forward, forward with fused pooling, data gradient with ReLU mask and accumulation -- at the real layer sizes,
+    where the 512-position blocks, the weight-slice ring and the per-tap vmcnt counts run for hundreds of steps.  patch32
+    itself is compared with the fp32 reference in the cases above (and p512 at small shapes there too)."""
+    from ssd_object_detection_amd import _lib
+    from tests.conv_cases import plan_name
+    B, H, W, Cin, Cout = case
+    g = torch.Generator(device="cuda").manual_seed(H + Cin)
+    x = torch.relu(torch.randn((B, H, W, Cin), generator=g, device="cuda")).bfloat16()
+    w = (torch.randn((Cout, 3, 3, Cin), generator=g, device="cuda") / np.sqrt(9 * Cin)).bfloat16()
+    bias = torch.randn((Cout,), generator=g, device="cuda") * 0.1
+    dy = torch.randn((B, H, W, Cout), generator=g, device="cuda").bfloat16()
+    base = torch.randn((B, H, W, Cin), generator=g, device="cuda").bfloat16()
+    w_t = ops.weight_transpose(w)
+    L = _lib.lib()
+    outs, names = [], []
+    for v in (0, 2):
+        assert L.ssd_dev_knob(b"SSD_CONV_P512", v) == 0
+        try:
+            names.append(plan_name(L, L.ssd_conv2d_fwd_plan(B, H, W, Cin, Cout, 3, 1, 1, 1, H, W, 0, 1 << 25)))
+            y = ops.conv2d_fwd(x, w, bias, 1, 1, 1, H, W, True)
+            yp = ops.conv2d_fwd_pool(x, w, bias, 1, 1, 1, H, W, True, True)
+            acc = base.clone()
+            ops.conv2d_bwd_data(dy, w_t, x, (B, H, W, Cin), 1, 1, 1, accumulate=True, out=acc)
+        finally:
+            L.ssd_dev_knob(b"SSD_CONV_P512", 1)
+        outs.append((y, yp[0], yp[1], yp[2], acc))
+    assert names[0].startswith("k_conv3x3_patch32") and names[1].startswith("k_conv3x3_p512"), names
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("shape", [0, 1, 2])
 def test_wgrad_patch_block_shapes(ops, shape):
     """Every block shape of the LDS-patch weight-gradient kernel (16x16, 6x40, 10x24) gives the same gradient;

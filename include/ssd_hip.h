@@ -217,6 +217,13 @@ int ssd_conv3x3_wino_fwd(const void* x, const void* u, const float* bias, void* 
                          int W, int Cin, int Cout, int relu, int Hp, int Wp, int in_shift, int w_shift, void* stream);
 int ssd_conv3x3_wino_bwd_data(const void* dy, const void* u_t, const void* relu_src, void* dx, int B, int H, int W, int Cin,
                               int Cout, int accumulate, int in_shift, int w_shift, void* stream);
+/* The 3x3 / stride 1 / pad 1 data gradient w.r.t. a POOLED map [B,H,W,Cin], carried on through the 2x2 / stride-2 max
+ * pooling that produced the map: dx_full[B,Hf,Wf,Cin] = ssd_maxpool2x2_bwd_argmax(pool_code, ssd_conv2d_bwd_data(...)) in
+ * one launch, bit-identical (the un-pooling runs in the convolution's store stage: no pooled gradient in HBM, no second
+ * kernel).  Served by the LDS-patch kernels only: SSD_ERR_UNSUPPORTED (nothing launched) for any other layer shape --
+ * call the two functions then. */
+int ssd_conv2d_bwd_data_unpool(const void* dy, const void* w_t, const void* relu_src, const void* pool_code, void* dx_full, int B,
+                               int H, int W, int Cin, int Cout_pad, int Hf, int Wf, void* ws, size_t ws_bytes, void* stream);
 /* dw f32 [Cout][k][k][Cin], dbias f32 [Cout] (or NULL) from x[B,H,W,Cin] and dy[B,Ho,Wo,ldy] (first Cout
  * channels).  Deterministic (fixed-order split reduction). */
 size_t ssd_conv2d_bwd_weight_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ldy, int ksize);

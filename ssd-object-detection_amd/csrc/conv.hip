@@ -2919,6 +2919,13 @@ int igemm_variant() {                       // SSD_CONV_VARIANT=0: register-stag
 }
 
 template <int EPI>
+bool staged_ok_host(const ConvGeom& g, const Epilogue& ep) {
+    if (ep.slab) return false;
+    if (EPI == EPI_HEAD) return true;
+    return (g.N & 7) == 0 && (ep.ldo & 7) == 0;
+}
+
+template <int EPI>
 int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue& ep_in, hipStream_t s, void* ws = nullptr,
                  size_t ws_bytes = 0, bool* pooled = nullptr, int* plan = nullptr) {
     const bf16_raw* xp = static_cast<const bf16_raw*>(x);
@@ -2930,7 +2937,7 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
     if constexpr (EPI != EPI_HEAD) {
         if (knob("SSD_CONV_C64", 2) && igemm_variant() >= 1 && g.KH == 3 && g.KW == 3 && g.mul == 1 && g.div == 1 && g.pad_t == 1 &&
             g.pad_l == 1 && g.C == 64 && g.N == 64 && g.ldw == 576 && g.H == g.Ho && g.W == g.Wo && g.H >= 16 && g.W >= 16 &&
-            !ep.accumulate && (ep.ldo & 7) == 0 && (long long)g.B * g.H * g.W * 64 < (1ll << 31) - 16) {
+            !ep.accumulate && !ep.up_out && (ep.ldo & 7) == 0 && (long long)g.B * g.H * g.W * 64 < (1ll << 31) - 16) {
             if (EPI == EPI_FWD && !ep.out && !(pooled && ep.pool_out)) return SSD_ERR_VALUE;
             if (knob("SSD_CONV_C64", 2) >= 2) {             // 8 x 16 blocks, two workgroups per CU
                 const int tiles_x = (g.Wo + 15) / 16, tiles_y = (g.Ho + C64B_ROWS - 1) / C64B_ROWS;
@@ -2986,6 +2993,7 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
             } while (0)
             const bool can_pool = pooled && ep.pool_out && !flat && (g.N & 7) == 0 && (ep.ldo & 7) == 0 && !(g.ablate & 8);
             if (EPI == EPI_FWD && !ep.out && !can_pool) return SSD_ERR_VALUE;
+            if (ep.up_out && (!staged_ok_host<EPI>(g, ep) || (g.ablate & 8))) return SSD_ERR_UNSUPPORTED;   // un-pooling lives in the staged store
             // 512 px x 128 channels, one workgroup per CU: from 256 input channels on (eight 32-channel chunks amortise its longer
             // prologue / epilogue; measured per layer in DESIGN.md section 9).  SSD_CONV_P512: 0 never, 1 (default) that rule, 2 always
             const int p512 = knob("SSD_CONV_P512", 1);
@@ -3016,6 +3024,7 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
             return ssd_launch_status();
         }
         if (EPI == EPI_FWD && !ep.out) return SSD_ERR_VALUE;     // pool-only needs a pooling kernel
+        if (ep.up_out) return SSD_ERR_UNSUPPORTED;
         if (g.N <= 64) {
             const size_t lds = 2 * 64 * 128 + PATCH_BYTES;
             auto kern = k_conv3x3_patch<64, EPI>;
@@ -3032,6 +3041,7 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
         return ssd_launch_status();
     }
     if (EPI == EPI_FWD && !ep.out) return SSD_ERR_VALUE;         // pool-only needs a pooling kernel
+    if (ep.up_out) return SSD_ERR_UNSUPPORTED;                   // only the LDS-patch kernels un-pool in their epilogue
     if (igemm_variant() >= 1) {
         // tile choice: the CU ingests ~28 B/clk from L2, so MACs per staged byte decide the ceiling: prefer the
         // largest tile that still gives every CU work (>= ~2 workgroups per CU), SSD_CONV_TILE overrides (testing)
@@ -3230,15 +3240,29 @@ int ssd_conv2d_head_fwd(const void* x, const void* w, const float* bias, void* l
 
 static int conv2d_bwd_data_impl(const void* dy, const void* w_t, const void* relu_src, void* dx, int B, int H, int W, int Cin,
                                 int Cout_pad, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int accumulate,
-                                void* ws, size_t ws_bytes, void* stream, int* plan) {
+                                void* ws, size_t ws_bytes, void* stream, int* plan, const void* up_code = nullptr,
+                                void* up_dx = nullptr, int up_h = 0, int up_w = 0) {
     // dy: [B,Ho,Wo,Cout_pad]; w_t: [Cin][k][k][Cout_pad] (ssd_weight_transpose); dx, relu_src: [B,H,W,Cin]
-    if (!dy || !w_t || !dx || !geom_ok(B, Ho, Wo, Cout_pad, H, W, Cin, ksize) || stride <= 0) return SSD_ERR_VALUE;
+    if (!dy || !w_t || (!dx && !up_dx) || !geom_ok(B, Ho, Wo, Cout_pad, H, W, Cin, ksize) || stride <= 0) return SSD_ERR_VALUE;
     const ConvGeom g = make_geom(B, Ho, Wo, Cout_pad, H, W, Cin, ksize, ksize, 1, stride, ksize - 1 - pad_t,
                                  ksize - 1 - pad_l);
     Epilogue ep = {};
     ep.out = static_cast<bf16_raw*>(dx); ep.ldo = Cin; ep.mask_src = static_cast<const bf16_raw*>(relu_src);
     ep.accumulate = accumulate;
+    ep.up_code = static_cast<const unsigned*>(up_code); ep.up_out = static_cast<bf16_raw*>(up_dx); ep.up_h = up_h; ep.up_w = up_w;
     return launch_igemm<EPI_DGRAD>(dy, w_t, g, ep, (hipStream_t)stream, ws, ws_bytes, nullptr, plan);
+}
+
+int ssd_conv2d_bwd_data_unpool(const void* dy, const void* w_t, const void* relu_src, const void* pool_code, void* dx_full, int B,
+                               int H, int W, int Cin, int Cout_pad, int Hf, int Wf, void* ws, size_t ws_bytes, void* stream) {
+    // 3x3 / stride 1 / pad 1 data gradient w.r.t. a POOLED map [B,H,W,Cin], carried on through the 2x2 / stride-2 max pooling
+    // that produced the map (pool_code [B,H,W,Cin/8] of ssd_maxpool2x2_fwd_argmax / ssd_conv2d_fwd_pool): dx_full [B,Hf,Wf,Cin]
+    if (!pool_code || !dx_full || Cin % 8 || Hf <= 0 || Wf <= 0) return SSD_ERR_VALUE;
+    if ((H != Hf / 2 && H != (Hf + 1) / 2) || (W != Wf / 2 && W != (Wf + 1) / 2)) return SSD_ERR_VALUE;
+    if (2 * H < Hf || 2 * W < Wf) return SSD_ERR_UNSUPPORTED;     // VALID pooling of an odd size: the uncovered row / column is not written here
+    if ((long long)B * Hf * Wf * Cin >= (1ll << 32)) return SSD_ERR_VALUE;
+    return conv2d_bwd_data_impl(dy, w_t, relu_src, nullptr, B, H, W, Cin, Cout_pad, 3, 1, 1, 1, H, W, 0, ws, ws_bytes, stream, nullptr,
+                                pool_code, dx_full, Hf, Wf);
 }
 
 int ssd_conv2d_bwd_data(const void* dy, const void* w_t, const void* relu_src, void* dx, int B, int H, int W, int Cin,

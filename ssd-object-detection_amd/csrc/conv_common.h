@@ -87,6 +87,13 @@ struct Epilogue {
     bf16_raw* pool_out;                      // [B][pool_h][pool_w][N] or null
     unsigned* pool_code;                     // [B][pool_h][pool_w][N/8]
     int pool_h, pool_w;
+    // DGRAD, kernels with the staged epilogue only: the result is the gradient of a POOLED map; instead of storing it (out
+    // may be null) route it through the 2x2 / stride-2 max pooling behind it (the winner codes of k_maxpool_fwd_argmax) and
+    // store the full-resolution gradient -- k_maxpool_bwd_argmax computed in the epilogue, without the round trip of the
+    // pooled gradient through HBM and without the launch
+    const unsigned* up_code;                 // [B][Ho][Wo][N/8] or null
+    bf16_raw* up_out;                        // [B][up_h][up_w][N]
+    int up_h, up_w;
 };
 
 __device__ __forceinline__ float bf2f(bf16_raw v) { return __uint_as_float((unsigned)v << 16); }
@@ -277,6 +284,30 @@ __device__ __forceinline__ void staged_store(char* smem, const ConvGeom& g, cons
                         return val;
                     };
                     v.x = gate(v.x, mk.x); v.y = gate(v.y, mk.y); v.z = gate(v.z, mk.z); v.w = gate(v.w, mk.w);
+                }
+            }
+            if constexpr (EPI == EPI_DGRAD) {
+                if (ep.up_code) {                             // un-pool: the four positions of the window, winner or zero
+                    const int b = fdiv(m, g.d_hw);
+                    const int rem = m - b * g.d_hw.d;
+                    const int oy = fdiv(rem, g.d_w), ox = rem - oy * g.d_w.d;
+                    const unsigned cw = ep.up_code[(long long)m * (g.N >> 3) + (n >> 3)];
+                    const unsigned gw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int iy = 2 * oy + (q >> 1), ix = 2 * ox + (q & 1);
+                        if (iy >= ep.up_h || ix >= ep.up_w) continue;
+                        unsigned w4[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const unsigned lo = ((cw >> (8 * k)) & 15u) == (unsigned)q ? 0x0000ffffu : 0u;
+                            const unsigned hi = ((cw >> (8 * k + 4)) & 15u) == (unsigned)q ? 0xffff0000u : 0u;
+                            w4[k] = gw[k] & (lo | hi);
+                        }
+                        *reinterpret_cast<uint4*>(ep.up_out + (((long long)b * ep.up_h + iy) * ep.up_w + ix) * g.N + n) =
+                            make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                    }
+                    if (!ep.out) continue;
                 }
             }
             *reinterpret_cast<uint4*>(ep.out + o) = v;

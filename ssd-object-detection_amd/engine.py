@@ -106,6 +106,7 @@ class SSDEngine:
         self.step_count = 0
         self.skip_fullres = os.environ.get("SSD_SKIP_FULLRES", "1") == "1"   # pooled convs store the pooled map only
         self.pool_only = {}                    # node -> whether a pool-only kernel serves it (learned at the first call)
+        self.fuse_unpool = {} if os.environ.get("SSD_FUSE_UNPOOL", "1") == "1" else None    # node -> data gradient un-pools itself
 
     # ---------------------------------------------------------------- static planning
     def _plan_shapes(self):
@@ -452,13 +453,15 @@ class SSDEngine:
             head_dgrad(lvl, self._ws)
         opt_bucket(None)
         # trunk, last layer first
+        unpooled = set()                          # pooling nodes whose backward pass ran inside the next convolution's data gradient
         for i in range(len(self.nodes) - 1, -1, -1):
             nd = self.nodes[i]
             g_out = gacts[i + 1]
             assert written[i + 1]
             if nd["kind"] == "pool":
                 assert not written[i], "a pooled activation cannot also feed a head (the pool gradient overwrites)"
-                ops.maxpool2x2_bwd_argmax(c["pool_code"][i], g_out, acts[i].shape, out=gacts[i])
+                if i not in unpooled:                 # (else the convolution behind the pooling already wrote gacts[i])
+                    ops.maxpool2x2_bwd_argmax(c["pool_code"][i], g_out, acts[i].shape, out=gacts[i])
                 written[i] = True
                 continue
             wt, bt = self.conv_params[i]
@@ -471,8 +474,23 @@ class SSDEngine:
             prev_is_relu_conv = self.nodes[i - 1]["kind"] == "conv"
             if i in head_done:                    # a large head wrote gacts[i] on the side stream: accumulate after it
                 main.wait_event(head_done.pop(i))
-            ops.conv2d_bwd_data(g_out, self.w_t[i], acts[i] if prev_is_relu_conv else None, acts[i].shape, nd["stride"],
-                                nd["pt"], nd["pl"], accumulate=written[i], out=gacts[i], ws=self._ws)
+            # a 3x3 / stride-1 convolution right behind a pooling: its data gradient is carried through the pooling in the
+            # convolution's own store stage (no pooled gradient in HBM, no pooling-backward launch) where an LDS-patch kernel
+            # serves the layer; learned at the first call, like pool_only
+            fused = False
+            if (self.fuse_unpool is not None and self.fuse_unpool.get(i, True) and self.nodes[i - 1]["kind"] == "pool" and not written[i] and not written[i - 1]
+                    and nd["k"] == 3 and nd["stride"] == 1 and nd["pt"] == 1 and nd["pl"] == 1):
+                try:
+                    ops.conv2d_bwd_data_unpool(g_out, self.w_t[i], None, c["pool_code"][i - 1], tuple(gacts[i - 1].shape),
+                                               out=gacts[i - 1], ws=self._ws)
+                    fused = True
+                    unpooled.add(i - 1)
+                except NotImplementedError:       # SSD_ERR_UNSUPPORTED: nothing was launched
+                    pass
+                self.fuse_unpool[i] = fused
+            if not fused:
+                ops.conv2d_bwd_data(g_out, self.w_t[i], acts[i] if prev_is_relu_conv else None, acts[i].shape, nd["stride"],
+                                    nd["pt"], nd["pl"], accumulate=written[i], out=gacts[i], ws=self._ws)
             written[i] = True
             opt_bucket(i)
         assert not opt_at

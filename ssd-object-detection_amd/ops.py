@@ -338,6 +338,26 @@ def conv2d_bwd_data(dy, w_t, relu_src, x_shape, stride, pad_t, pad_l, accumulate
     return out
 
 
+def conv2d_bwd_data_unpool(dy, w_t, relu_src, pool_code, full_shape, out=None, ws=None):
+    """conv2d_bwd_data (3x3 / stride 1 / pad 1) w.r.t. a pooled map followed by maxpool2x2_bwd_argmax, in one launch: returns the
+    gradient of the map BEFORE the pooling ([B,Hf,Wf,Cin]).  Raises NotImplementedError (SSD_ERR_UNSUPPORTED, nothing launched)
+    when the layer is not served by an LDS-patch kernel: use the two calls then."""
+    L = _lib.lib()
+    _bf(dy); _bf(w_t)
+    B, Hf, Wf, Cin = full_shape
+    _, H, W, cpad = dy.shape
+    assert w_t.shape == (Cin, 3, 3, cpad) and pool_code.shape == (B, H, W, Cin // 8) and pool_code.dtype == torch.int32
+    if out is None:
+        out = torch.empty(full_shape, dtype=torch.bfloat16, device=dy.device)
+    wbuf = _splitk_ws(ws)
+    rc = L.ssd_conv2d_bwd_data_unpool(_ptr(dy), _ptr(w_t), _ptr(relu_src), _ptr(pool_code), _ptr(out), B, H, W, Cin, cpad, Hf, Wf,
+                                      _ptr(wbuf), wbuf.numel(), _stream())
+    if rc == _lib.SSD_ERR_UNSUPPORTED:
+        raise NotImplementedError("no LDS-patch kernel for this layer")
+    _lib.check(rc)
+    return out
+
+
 def wino_supported(B, H, W, Cin, Cout):
     """Shapes served by the Winograd F(2x2,3x3) kernels (3x3 / stride 1 / pad 1 only)."""
     return bool(_lib.lib().ssd_conv3x3_wino_supported(B, H, W, Cin, Cout))

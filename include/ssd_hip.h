@@ -217,6 +217,18 @@ int ssd_conv3x3_wino_fwd(const void* x, const void* u, const float* bias, void* 
                          int W, int Cin, int Cout, int relu, int Hp, int Wp, int in_shift, int w_shift, void* stream);
 int ssd_conv3x3_wino_bwd_data(const void* dy, const void* u_t, const void* relu_src, void* dx, int B, int H, int W, int Cin,
                               int Cout, int accumulate, int in_shift, int w_shift, void* stream);
+/* ReLU sign bits.  ssd_conv2d_fwd_relubits = ssd_conv2d_fwd (relu = 1) that also writes one byte per pixel and 8 output
+ * channels (bit k: channel 8c + k > 0), relu_bits [B*Ho*Wo][Cout/8]; ssd_conv2d_bwd_data_bits = ssd_conv2d_bwd_data with
+ * its ReLU mask read from such bytes instead of the bf16 activation (relu_src): identical results, 16x fewer mask bytes --
+ * re-reading whole activations for their sign cost the data gradients 13-130 us each.  Written / read in the staged store
+ * of the kernels (and by the image-layer kernel): SSD_ERR_UNSUPPORTED, nothing launched, where a call resolves to a kernel
+ * without it (split-K + finalize, scattered epilogues) -- use the plain functions there. */
+int ssd_conv2d_fwd_relubits(const void* x, const void* w, const float* bias, void* y, void* relu_bits, int B, int H, int W, int Cin,
+                            int Cout, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, void* ws, size_t ws_bytes,
+                            void* stream);
+int ssd_conv2d_bwd_data_bits(const void* dy, const void* w_t, const void* relu_bits, void* dx, int B, int H, int W, int Cin,
+                             int Cout_pad, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int accumulate, void* ws,
+                             size_t ws_bytes, void* stream);
 /* The 3x3 / stride 1 / pad 1 data gradient w.r.t. a POOLED map [B,H,W,Cin], carried on through the 2x2 / stride-2 max
  * pooling that produced the map: dx_full[B,Hf,Wf,Cin] = ssd_maxpool2x2_bwd_argmax(pool_code, ssd_conv2d_bwd_data(...)) in
  * one launch, bit-identical (the un-pooling runs in the convolution's store stage: no pooled gradient in HBM, no second

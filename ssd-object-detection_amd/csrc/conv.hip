@@ -1420,7 +1420,7 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
         // round trip with the matrix cores idle (300 us of the 630 us this kernel took)
         uint4 mk[4];
         int mk_m[4];
-        const bool premask = EPI == EPI_DGRAD && ep.mask_src != nullptr && !(g.ablate & 128);
+        const bool premask = EPI == EPI_DGRAD && (ep.mask_src != nullptr || ep.mask_bits != nullptr) && !(g.ablate & 128);
         if constexpr (EPI == EPI_DGRAD) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -1428,7 +1428,10 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
                 const int y = y0 + (row >> 4), xx = x0 + (row & 15);
                 mk_m[i] = (y < g.Ho && xx < g.Wo) ? (b * g.Ho + y) * g.Wo + xx : -1;
                 mk[i] = make_uint4(0, 0, 0, 0);
-                if (premask && mk_m[i] >= 0) mk[i] = *reinterpret_cast<const uint4*>(ep.mask_src + (long long)mk_m[i] * ep.ldo + ch * 8);
+                if (premask && mk_m[i] >= 0) {
+                    if (ep.mask_bits) mk[i].x = ep.mask_bits[(long long)mk_m[i] * 8 + ch];       // sign bits: one byte instead of 16
+                    else mk[i] = *reinterpret_cast<const uint4*>(ep.mask_src + (long long)mk_m[i] * ep.ldo + ch * 8);
+                }
             }
         }
         const int tnext = block_of(it + 1);
@@ -1503,7 +1506,8 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
                     const int idx = i * 256 + tid, row = idx >> 3, ch = idx & 7;
                     if (mk_m[i] < 0) continue;
                     uint4 v = *reinterpret_cast<const uint4*>(st + row * 128 + (((ch ^ row) & 7) << 4));
-                    v.x = gate(v.x, mk[i].x); v.y = gate(v.y, mk[i].y); v.z = gate(v.z, mk[i].z); v.w = gate(v.w, mk[i].w);
+                    if (ep.mask_bits) v = gate_bits8(v, mk[i].x);
+                    else { v.x = gate(v.x, mk[i].x); v.y = gate(v.y, mk[i].y); v.z = gate(v.z, mk[i].z); v.w = gate(v.w, mk[i].w); }
                     *reinterpret_cast<uint4*>(ep.out + (long long)mk_m[i] * ep.ldo + ch * 8) = v;
                 }
             }
@@ -1530,7 +1534,7 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
 // two fully coalesced 1 KiB stores (16 consecutive NHWC pixels are contiguous).
 __global__ __launch_bounds__(512) void k_conv0_fwd(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ w,
                                                    const float* __restrict__ bias, bf16_raw* __restrict__ out, ConvGeom g,
-                                                   int relu, int tiles_x, int tiles_y) {
+                                                   int relu, int tiles_x, int tiles_y, unsigned char* __restrict__ relu_bits) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 6 * 1024 + 8 * 2048];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1636,8 +1640,10 @@ __global__ __launch_bounds__(512) void k_conv0_fwd(const bf16_raw* __restrict__ 
                 const int px = idx >> 3, ch = idx & 7;
                 const uint4 v = *reinterpret_cast<const uint4*>(stage + px * 128 + ((ch ^ (px & 7)) << 4));
                 const int xx = x0 + px;
-                if (y < g.Ho && xx < g.Wo)          // N == 64 (host check): every chunk of the pixel is stored
+                if (y < g.Ho && xx < g.Wo) {        // N == 64 (host check): every chunk of the pixel is stored
                     *reinterpret_cast<uint4*>(out + ((unsigned)((b * g.Ho + y) * g.Wo + xx) * 64u + (unsigned)(ch * 8))) = v;
+                    if (relu_bits) relu_bits[(unsigned)((b * g.Ho + y) * g.Wo + xx) * 8u + (unsigned)ch] = (unsigned char)relu_bits8(v);
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging tile is reused by the second row
         }
@@ -2993,7 +2999,8 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
             } while (0)
             const bool can_pool = pooled && ep.pool_out && !flat && (g.N & 7) == 0 && (ep.ldo & 7) == 0 && !(g.ablate & 8);
             if (EPI == EPI_FWD && !ep.out && !can_pool) return SSD_ERR_VALUE;
-            if (ep.up_out && (!staged_ok_host<EPI>(g, ep) || (g.ablate & 8))) return SSD_ERR_UNSUPPORTED;   // un-pooling lives in the staged store
+            if ((ep.up_out || ep.relu_bits || ep.mask_bits) && (!staged_ok_host<EPI>(g, ep) || (g.ablate & 8)))
+                return SSD_ERR_UNSUPPORTED;                      // un-pooling and the sign bits live in the staged store
             // 512 px x 128 channels, one workgroup per CU: from 256 input channels on (eight 32-channel chunks amortise its longer
             // prologue / epilogue; measured per layer in DESIGN.md section 9).  SSD_CONV_P512: 0 never, 1 (default) that rule, 2 always
             const int p512 = knob("SSD_CONV_P512", 1);
@@ -3024,7 +3031,7 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
             return ssd_launch_status();
         }
         if (EPI == EPI_FWD && !ep.out) return SSD_ERR_VALUE;     // pool-only needs a pooling kernel
-        if (ep.up_out) return SSD_ERR_UNSUPPORTED;
+        if (ep.up_out || ep.relu_bits || ep.mask_bits) return SSD_ERR_UNSUPPORTED;
         if (g.N <= 64) {
             const size_t lds = 2 * 64 * 128 + PATCH_BYTES;
             auto kern = k_conv3x3_patch<64, EPI>;
@@ -3074,6 +3081,8 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
                 if (want > 1) { ksplit = (unsigned)want; ep.slab = static_cast<float*>(ws); ep.ksplit = (int)want; }
             }
         }
+        // the sign bits are written / read by the staged store only (not by the split-K finalize or the scattered epilogue)
+        if ((ep.relu_bits || ep.mask_bits) && (ksplit > 1 || !staged_ok_host<EPI>(g, ep) || (g.ablate & 8))) return SSD_ERR_UNSUPPORTED;
 #define SSD_LAUNCH_DMA(BM_, BN_)                                                                                   \
         do {                                                                                                       \
             constexpr int PT_ = (BM_ == 256 && BN_ == 256) ? SSD_PT256 : 4;                                         \
@@ -3130,6 +3139,7 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
         }
         return ssd_launch_status();
     }
+    if (ep.relu_bits || ep.mask_bits) return SSD_ERR_UNSUPPORTED;
     SSD_PLAN(g.N <= 64 ? SSD_PLAN_REG_64 : SSD_PLAN_REG_128);
     if (g.N <= 64) {
         const size_t lds = 2 * (128 + 64) * 128;
@@ -3165,7 +3175,7 @@ int ssd_dev_knob(const char* name, int value) {
 
 static int conv2d_fwd_impl(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
                            int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int relu, void* ws, size_t ws_bytes,
-                           void* stream, int* plan) {
+                           void* stream, int* plan, void* relu_bits = nullptr) {
     if (!x || !w || !y || !geom_ok(B, H, W, Cin, Ho, Wo, Cout, ksize) || stride <= 0) return SSD_ERR_VALUE;
     const ConvGeom g = make_geom(B, H, W, Cin, Ho, Wo, Cout, ksize, ksize, stride, 1, pad_t, pad_l);
     if (knob("SSD_CONV_FIRST", 1) && Cin == 8 && Cout == 64 && ksize == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && H == Ho &&
@@ -3174,11 +3184,12 @@ static int conv2d_fwd_impl(const void* x, const void* w, const float* bias, void
         const int tx = (Wo + 15) / 16, ty = (Ho + 15) / 16;
         hipLaunchKernelGGL(k_conv0_fwd, dim3((unsigned)(B * tx * ty < 768 ? B * tx * ty : 768)), dim3(512), 0, (hipStream_t)stream,
                            static_cast<const bf16_raw*>(x), static_cast<const bf16_raw*>(w), bias, static_cast<bf16_raw*>(y), g, relu,
-                           tx, ty);
+                           tx, ty, static_cast<unsigned char*>(relu_bits));
         return ssd_launch_status();
     }
     Epilogue ep = {};
     ep.bias = bias; ep.relu = relu; ep.out = static_cast<bf16_raw*>(y); ep.ldo = Cout;
+    ep.relu_bits = static_cast<unsigned char*>(relu_bits);
     return launch_igemm<EPI_FWD>(x, w, g, ep, (hipStream_t)stream, ws, ws_bytes, nullptr, plan);
 }
 
@@ -3241,7 +3252,7 @@ int ssd_conv2d_head_fwd(const void* x, const void* w, const float* bias, void* l
 static int conv2d_bwd_data_impl(const void* dy, const void* w_t, const void* relu_src, void* dx, int B, int H, int W, int Cin,
                                 int Cout_pad, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int accumulate,
                                 void* ws, size_t ws_bytes, void* stream, int* plan, const void* up_code = nullptr,
-                                void* up_dx = nullptr, int up_h = 0, int up_w = 0) {
+                                void* up_dx = nullptr, int up_h = 0, int up_w = 0, const void* mask_bits = nullptr) {
     // dy: [B,Ho,Wo,Cout_pad]; w_t: [Cin][k][k][Cout_pad] (ssd_weight_transpose); dx, relu_src: [B,H,W,Cin]
     if (!dy || !w_t || (!dx && !up_dx) || !geom_ok(B, Ho, Wo, Cout_pad, H, W, Cin, ksize) || stride <= 0) return SSD_ERR_VALUE;
     const ConvGeom g = make_geom(B, Ho, Wo, Cout_pad, H, W, Cin, ksize, ksize, 1, stride, ksize - 1 - pad_t,
@@ -3250,7 +3261,26 @@ static int conv2d_bwd_data_impl(const void* dy, const void* w_t, const void* rel
     ep.out = static_cast<bf16_raw*>(dx); ep.ldo = Cin; ep.mask_src = static_cast<const bf16_raw*>(relu_src);
     ep.accumulate = accumulate;
     ep.up_code = static_cast<const unsigned*>(up_code); ep.up_out = static_cast<bf16_raw*>(up_dx); ep.up_h = up_h; ep.up_w = up_w;
+    ep.mask_bits = static_cast<const unsigned char*>(mask_bits);
     return launch_igemm<EPI_DGRAD>(dy, w_t, g, ep, (hipStream_t)stream, ws, ws_bytes, nullptr, plan);
+}
+
+int ssd_conv2d_fwd_relubits(const void* x, const void* w, const float* bias, void* y, void* relu_bits, int B, int H, int W, int Cin,
+                            int Cout, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, void* ws, size_t ws_bytes,
+                            void* stream) {
+    // ssd_conv2d_fwd with ReLU that also writes the sign bits of its output: relu_bits [B*Ho*Wo][Cout/8] bytes
+    if (!relu_bits || Cout % 8) return SSD_ERR_VALUE;
+    return conv2d_fwd_impl(x, w, bias, y, B, H, W, Cin, Cout, ksize, stride, pad_t, pad_l, Ho, Wo, 1, ws, ws_bytes, stream, nullptr,
+                           relu_bits);
+}
+
+int ssd_conv2d_bwd_data_bits(const void* dy, const void* w_t, const void* relu_bits, void* dx, int B, int H, int W, int Cin,
+                             int Cout_pad, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int accumulate, void* ws,
+                             size_t ws_bytes, void* stream) {
+    // ssd_conv2d_bwd_data with the ReLU mask given as sign bits ([B*H*W][Cin/8] bytes of ssd_conv2d_fwd_relubits)
+    if (!relu_bits || Cin % 8) return SSD_ERR_VALUE;
+    return conv2d_bwd_data_impl(dy, w_t, nullptr, dx, B, H, W, Cin, Cout_pad, ksize, stride, pad_t, pad_l, Ho, Wo, accumulate, ws,
+                                ws_bytes, stream, nullptr, nullptr, nullptr, 0, 0, relu_bits);
 }
 
 int ssd_conv2d_bwd_data_unpool(const void* dy, const void* w_t, const void* relu_src, const void* pool_code, void* dx_full, int B,

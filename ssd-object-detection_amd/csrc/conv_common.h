@@ -94,7 +94,31 @@ struct Epilogue {
     const unsigned* up_code;                 // [B][Ho][Wo][N/8] or null
     bf16_raw* up_out;                        // [B][up_h][up_w][N]
     int up_h, up_w;
+    // ReLU sign bits, one byte per (pixel, 8 channels): bit k = channel 8c + k of the pixel is > 0.  FWD (kernels with the
+    // staged store, k_conv0_fwd): written next to the activation.  DGRAD: read INSTEAD of mask_src -- the data gradients
+    // spent 13-130 us each on re-reading whole bf16 activations for their sign (16x the bytes, exposed at the store tail)
+    unsigned char* relu_bits;                // FWD out [M][N/8] or null
+    const unsigned char* mask_bits;          // DGRAD in [M][N/8] or null
 };
+
+// bit k set <=> bf16 element k of the 16-byte chunk is > 0
+__device__ __forceinline__ unsigned relu_bits8(const uint4& v) {
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    unsigned b = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        b |= (__uint_as_float(w[k] << 16) > 0.f ? 1u : 0u) << (2 * k);
+        b |= (__uint_as_float(w[k] & 0xffff0000u) > 0.f ? 2u : 0u) << (2 * k);
+    }
+    return b;
+}
+// zero the elements of a chunk whose bit is clear
+__device__ __forceinline__ uint4 gate_bits8(uint4 v, unsigned b) {
+    unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k] &= ((b >> (2 * k)) & 1u ? 0x0000ffffu : 0u) | ((b >> (2 * k + 1)) & 1u ? 0xffff0000u : 0u);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
 
 __device__ __forceinline__ float bf2f(bf16_raw v) { return __uint_as_float((unsigned)v << 16); }
 __device__ __forceinline__ bf16_raw f2bf(float f) {
@@ -284,7 +308,12 @@ __device__ __forceinline__ void staged_store(char* smem, const ConvGeom& g, cons
                         return val;
                     };
                     v.x = gate(v.x, mk.x); v.y = gate(v.y, mk.y); v.z = gate(v.z, mk.z); v.w = gate(v.w, mk.w);
+                } else if (ep.mask_bits) {
+                    v = gate_bits8(v, ep.mask_bits[(long long)m * (g.N >> 3) + (n >> 3)]);
                 }
+            }
+            if constexpr (EPI == EPI_FWD) {
+                if (ep.relu_bits) ep.relu_bits[(long long)m * (g.N >> 3) + (n >> 3)] = (unsigned char)relu_bits8(v);
             }
             if constexpr (EPI == EPI_DGRAD) {
                 if (ep.up_code) {                             // un-pool: the four positions of the window, winner or zero

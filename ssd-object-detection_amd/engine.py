@@ -107,6 +107,10 @@ class SSDEngine:
         self.skip_fullres = os.environ.get("SSD_SKIP_FULLRES", "1") == "1"   # pooled convs store the pooled map only
         self.pool_only = {}                    # node -> whether a pool-only kernel serves it (learned at the first call)
         self.fuse_unpool = {} if os.environ.get("SSD_FUSE_UNPOOL", "1") == "1" else None    # node -> data gradient un-pools itself
+        # activation index -> its sign bits are written by the forward kernel (learned at the first call); data-gradient
+        # key (str) -> that kernel reads them
+        self.relu_bits = {} if os.environ.get("SSD_RELU_BITS", "1") == "1" else None
+        self.bits_valid = set()
 
     # ---------------------------------------------------------------- static planning
     def _plan_shapes(self):
@@ -264,7 +268,11 @@ class SSDEngine:
                       for (_, h, _), npad in zip(self.fm, self.head_npad)]
             pool_code = {i: torch.empty((B, nd["hout"], nd["hout"], nd["cout"] // 8), dtype=torch.int32, device=dev)
                          for i, nd in enumerate(self.nodes) if nd["kind"] == "pool"}
-            c = dict(acts=acts, gacts=gacts, loc=loc, conf=conf, packed=packed, pool_code=pool_code)
+            # ReLU sign bits of every convolution output (one byte per pixel and 8 channels): what the data gradients read
+            # instead of the bf16 activation
+            rbits = {i + 1: torch.empty((B, nd["hout"], nd["hout"], nd["cout"] // 8), dtype=torch.uint8, device=dev)
+                     for i, nd in enumerate(self.nodes) if nd["kind"] == "conv" and nd["cout"] % 8 == 0}
+            c = dict(acts=acts, gacts=gacts, loc=loc, conf=conf, packed=packed, pool_code=pool_code, rbits=rbits)
             self._act_cache = {B: c}              # keep one batch size resident
         return c
 
@@ -303,6 +311,7 @@ class SSDEngine:
             ops.conv2d_head_fwd(acts[ni + 1], self.view(wt, self.param_bf16), self.view(bt, self.param), c["loc"],
                                 c["conf"], self.num_priors[lvl], self.classes, self.level_off[lvl], ws=ws)
 
+        self.bits_valid = set()
         for i, nd in enumerate(self.nodes):
             if nd["kind"] == "conv":
                 wt, bt = self.conv_params[i]
@@ -323,8 +332,19 @@ class SSDEngine:
                     if not pool_only:
                         ops.conv2d_fwd_pool(*args, **kw)
                 else:
-                    ops.conv2d_fwd(acts[i], self.view(wt, self.param_bf16), self.view(bt, self.param), nd["stride"],
-                                   nd["pt"], nd["pl"], nd["hout"], nd["hout"], True, out=acts[i + 1], ws=self._ws)
+                    args = (acts[i], self.view(wt, self.param_bf16), self.view(bt, self.param), nd["stride"], nd["pt"], nd["pl"],
+                            nd["hout"], nd["hout"])
+                    done = False
+                    if self.relu_bits is not None and self.relu_bits.get(i + 1, True) and (i + 1) in c["rbits"]:
+                        try:
+                            ops.conv2d_fwd_relubits(*args, c["rbits"][i + 1], out=acts[i + 1], ws=self._ws)
+                            done = True
+                            self.bits_valid.add(i + 1)
+                        except NotImplementedError:   # SSD_ERR_UNSUPPORTED: nothing launched
+                            pass
+                        self.relu_bits[i + 1] = done
+                    if not done:
+                        ops.conv2d_fwd(*args, True, out=acts[i + 1], ws=self._ws)
             elif i == 0 or self.nodes[i - 1]["kind"] != "conv":
                 ops.maxpool2x2_fwd_argmax(acts[i], out=acts[i + 1], code=c["pool_code"][i],
                                           same=nd["hout"] * 2 != nd["hin"])
@@ -418,10 +438,22 @@ class SSDEngine:
             if lvl not in big or not pack_side:
                 pack(lvl)
 
+        def masked_dgrad(key, dy, w_t, a, stride, pt, pl, accumulate, ws):
+            """Data gradient w.r.t. activation a (index), masked by its ReLU sign: from the sign bits where this step's forward
+            pass wrote them and the kernel reads them (learned per call site), else from the bf16 activation."""
+            if self.relu_bits is not None and a in self.bits_valid and self.relu_bits.get(key, True):
+                try:
+                    ops.conv2d_bwd_data_bits(dy, w_t, c["rbits"][a], acts[a].shape, stride, pt, pl, accumulate=accumulate,
+                                             out=gacts[a], ws=ws)
+                    self.relu_bits[key] = True
+                    return
+                except NotImplementedError:
+                    self.relu_bits[key] = False
+            ops.conv2d_bwd_data(dy, w_t, acts[a], acts[a].shape, stride, pt, pl, accumulate=accumulate, out=gacts[a], ws=ws)
+
         def head_dgrad(lvl, ws):
             ni = self.fm[lvl][0]
-            ops.conv2d_bwd_data(packed[lvl], self.head_w_t[lvl], acts[ni + 1], acts[ni + 1].shape, 1, 1, 1,
-                                accumulate=False, out=gacts[ni + 1], ws=ws)
+            masked_dgrad("head%d" % lvl, packed[lvl], self.head_w_t[lvl], ni + 1, 1, 1, 1, False, ws)
             written[ni + 1] = True
 
         def head_wgrad(lvl, ws):
@@ -488,9 +520,11 @@ class SSDEngine:
                 except NotImplementedError:       # SSD_ERR_UNSUPPORTED: nothing was launched
                     pass
                 self.fuse_unpool[i] = fused
-            if not fused:
-                ops.conv2d_bwd_data(g_out, self.w_t[i], acts[i] if prev_is_relu_conv else None, acts[i].shape, nd["stride"],
-                                    nd["pt"], nd["pl"], accumulate=written[i], out=gacts[i], ws=self._ws)
+            if not fused and prev_is_relu_conv:
+                masked_dgrad("conv%d" % i, g_out, self.w_t[i], i, nd["stride"], nd["pt"], nd["pl"], written[i], self._ws)
+            elif not fused:
+                ops.conv2d_bwd_data(g_out, self.w_t[i], None, acts[i].shape, nd["stride"], nd["pt"], nd["pl"],
+                                    accumulate=written[i], out=gacts[i], ws=self._ws)
             written[i] = True
             opt_bucket(i)
         assert not opt_at

@@ -338,6 +338,45 @@ def conv2d_bwd_data(dy, w_t, relu_src, x_shape, stride, pad_t, pad_l, accumulate
     return out
 
 
+def conv2d_fwd_relubits(x, w, bias, stride, pad_t, pad_l, Ho, Wo, bits, out=None, ws=None):
+    """conv2d_fwd with ReLU that also writes the sign bits of its output (uint8 [B,Ho,Wo,Cout/8]).  NotImplementedError
+    (SSD_ERR_UNSUPPORTED, nothing launched) where the layer's kernel has no staged store."""
+    L = _lib.lib()
+    _bf(x); _bf(w)
+    B, H, W, Cin = x.shape
+    Cout, k = w.shape[0], w.shape[1]
+    assert bits.dtype == torch.uint8 and bits.shape == (B, Ho, Wo, Cout // 8) and bits.is_contiguous()
+    if out is None:
+        out = torch.empty((B, Ho, Wo, Cout), dtype=torch.bfloat16, device=x.device)
+    wbuf = _splitk_ws(ws)
+    rc = L.ssd_conv2d_fwd_relubits(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), _ptr(bits), B, H, W, Cin, Cout, k, stride, pad_t, pad_l,
+                                   Ho, Wo, _ptr(wbuf), wbuf.numel(), _stream())
+    if rc == _lib.SSD_ERR_UNSUPPORTED:
+        raise NotImplementedError("this layer's kernel does not write sign bits")
+    _lib.check(rc)
+    return out
+
+
+def conv2d_bwd_data_bits(dy, w_t, bits, x_shape, stride, pad_t, pad_l, accumulate=False, out=None, ws=None):
+    """conv2d_bwd_data with the ReLU mask given as the sign bits of conv2d_fwd_relubits (same result, 16x fewer mask bytes)."""
+    L = _lib.lib()
+    _bf(dy); _bf(w_t)
+    B, H, W, Cin = x_shape
+    _, Ho, Wo, cpad = dy.shape
+    k = w_t.shape[1]
+    assert w_t.shape == (Cin, k, k, cpad) and bits.dtype == torch.uint8 and bits.shape == (B, H, W, Cin // 8)
+    if out is None:
+        assert not accumulate
+        out = torch.empty(x_shape, dtype=torch.bfloat16, device=dy.device)
+    wbuf = _splitk_ws(ws)
+    rc = L.ssd_conv2d_bwd_data_bits(_ptr(dy), _ptr(w_t), _ptr(bits), _ptr(out), B, H, W, Cin, cpad, k, stride, pad_t, pad_l, Ho, Wo,
+                                    1 if accumulate else 0, _ptr(wbuf), wbuf.numel(), _stream())
+    if rc == _lib.SSD_ERR_UNSUPPORTED:
+        raise NotImplementedError("this layer's kernel does not read sign bits")
+    _lib.check(rc)
+    return out
+
+
 def conv2d_bwd_data_unpool(dy, w_t, relu_src, pool_code, full_shape, out=None, ws=None):
     """conv2d_bwd_data (3x3 / stride 1 / pad 1) w.r.t. a pooled map followed by maxpool2x2_bwd_argmax, in one launch: returns the
     gradient of the map BEFORE the pooling ([B,Hf,Wf,Cin]).  Raises NotImplementedError (SSD_ERR_UNSUPPORTED, nothing launched)

@@ -3004,7 +3004,9 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
             // 512 px x 128 channels, one workgroup per CU: from 256 input channels on (eight 32-channel chunks amortise its longer
             // prologue / epilogue; measured per layer in DESIGN.md section 9).  SSD_CONV_P512: 0 never, 1 (default) that rule, 2 always
             const int p512 = knob("SSD_CONV_P512", 1);
-            if (p512 && g.C % 64 == 0 && g.N > 64 && (p512 >= 2 || g.C >= 256)) {
+            // (the heads' element-wise scatter epilogue has nothing to hide behind with one workgroup per CU: head 0, 38x38 x 512
+            //  channels, 385 vs 334 us; head 1, 1024 channels, 208 vs 222 us -- the 512-pixel kernel from 1024 channels on)
+            if (p512 && g.C % 64 == 0 && g.N > 64 && (p512 >= 2 || g.C >= (EPI == EPI_HEAD ? 1024 : 256))) {
                 const int ty32 = (g.Ho + 31) / 32;
                 const unsigned strips32 = (unsigned)(((long long)g.B * (g.H + 1) + 31) / 32);
                 const int rf = (!flat && !ep.pool_out && knob("SSD_CONV_PATCH_ROWFLAT", 1) && strips32 < (unsigned)(ty32 * g.B)) ? 1 : 0;

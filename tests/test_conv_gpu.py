@@ -289,7 +289,7 @@ def test_wgrad_padded_dy(ops):
     assert (db.cpu() - dy[..., :Cout].float().sum((0, 1, 2))).abs().max().item() <= 1e-3 * 30
 
 
-@pytest.mark.parametrize("shape", [(2, 5, 5, 64, 6), (2, 19, 19, 256, 4)])     # generic GEMM; k_conv3x3_p512 strip blocks (as head 0 / 1)
+@pytest.mark.parametrize("shape", [(2, 5, 5, 64, 6), (2, 19, 19, 256, 4), (2, 19, 19, 1024, 6)])   # generic GEMM; patch32 strip blocks (as head 0); k_conv3x3_p512 strip blocks (as head 1)
 def test_head_fwd_layout(ops, shape):
     """Fused loc+conf head writes the reference's Reshape/Concatenate layout (models/ssd_model.py:166-167)."""
     (B, H, W, Cin, n), C = shape, 81

@@ -262,6 +262,28 @@ __device__ __forceinline__ void staged_store(char* smem, const ConvGeom& g, cons
                                              PoolMap pool_index) {
     constexpr int CPR = BN / 8;                 // 16-byte chunks per tile row
     if constexpr (EPI == EPI_HEAD) {
+        // A pixel's loc run (per_cell x 4) and conf run (per_cell x classes) are contiguous in the outputs but only 2-byte
+        // aligned in general.  When the anchor counts are even (all six SSD levels: 4 or 6 per cell, even level offsets and
+        // anchor total) every run starts 4-byte aligned and has even length: two channels per store, 64 consecutive channel
+        // pairs of one pixel per wave-instruction -- half the store instructions of the element-wise form below
+        const bool pairs = !((ep.per_cell | ep.level_off | ep.anchors_total | ep.n_loc | ep.n_conf) & 1);
+        if (pairs) {
+            constexpr int ITER2 = BM * BN / (2 * NT);
+            for (int it = 0; it < ITER2; ++it) {
+                const int idx = it * NT + tid;
+                const int row = idx / (BN / 2), col = (idx - row * (BN / 2)) * 2;
+                const int n = n0 + col;
+                const int m = row_to_m(row);
+                if (m < 0 || n >= ep.n_loc + ep.n_conf) continue;
+                const unsigned val = *reinterpret_cast<const unsigned*>(smem + row * (BN * 2) + ((((col >> 3) ^ row) & (CPR - 1)) << 4) + (col & 7) * 2);
+                const int b = fdiv(m, g.d_hw);
+                const int pix = m - b * g.d_hw.d;
+                const long long anchor0 = (long long)b * ep.anchors_total + ep.level_off + (long long)pix * ep.per_cell;
+                if (n < ep.n_loc) *reinterpret_cast<unsigned*>(ep.loc + anchor0 * 4 + n) = val;
+                else *reinterpret_cast<unsigned*>(ep.conf + anchor0 * ep.classes + (n - ep.n_loc)) = val;
+            }
+            return;
+        }
         // element-wise, 64 consecutive channels of one pixel per wave-instruction
         constexpr int ITER = BM * BN / NT;
         for (int it = 0; it < ITER; ++it) {

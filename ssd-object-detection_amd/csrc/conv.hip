@@ -2881,6 +2881,17 @@ __global__ void k_head_grad_pack(const bf16_raw* __restrict__ dloc, const bf16_r
     const long long anchor0 = (long long)b * anchors_total + level_off + (long long)pix * per_cell;
     const bf16_raw* pl = dloc + anchor0 * 4;
     const bf16_raw* pc = dconf + anchor0 * classes - n_loc;
+    if (!((per_cell | level_off | anchors_total) & 1)) {      // even anchor counts: every run 4-byte aligned, two channels per load
+        unsigned w4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = ch * 8 + 2 * j;
+            w4[j] = n < n_loc ? *reinterpret_cast<const unsigned*>(pl + n)
+                              : (n < n_loc + n_conf ? *reinterpret_cast<const unsigned*>(pc + n) : 0u);
+        }
+        *reinterpret_cast<uint4*>(out + r * npad + ch * 8) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        return;
+    }
     bf16_raw v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {

@@ -47,10 +47,17 @@ __global__ void k_igemm_finalize(ConvGeom g, Epilogue ep) {
     const int m = (int)(idx / n4), n = (int)(idx - (long long)m * n4) * 4;
     const bool full = n + 3 < g.N;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int z = 0; z < ep.ksplit; ++z) {
-        const float* sl = ep.slab + ((long long)z * g.M + m) * g.N + n;
+    if (full && !(g.N & 3)) {                     // 16-byte aligned slab rows: one load per split (same order of additions)
+        for (int z = 0; z < ep.ksplit; ++z) {
+            const float4 t = *reinterpret_cast<const float4*>(ep.slab + ((long long)z * g.M + m) * g.N + n);
+            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        }
+    } else {
+        for (int z = 0; z < ep.ksplit; ++z) {
+            const float* sl = ep.slab + ((long long)z * g.M + m) * g.N + n;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (n + j < g.N) v[j] += sl[j];
+            for (int j = 0; j < 4; ++j) if (n + j < g.N) v[j] += sl[j];
+        }
     }
     if constexpr (EPI != EPI_DGRAD) {
         float b4[4];

@@ -220,6 +220,10 @@ __device__ __forceinline__ void conv_epilogue_rows(f32x4_t (&acc)[CT][PT], const
                 const int m = mrow[p];
                 if (m < 0) continue;
                 float* o = sl + (long long)m * g.N + n;
+                if (full && !(g.N & 3)) {                 // 16-byte aligned: one store
+                    *reinterpret_cast<float4*>(o) = make_float4(acc[c][p][0], acc[c][p][1], acc[c][p][2], acc[c][p][3]);
+                    continue;
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) if (n + j < g.N) o[j] = acc[c][p][j];
             }

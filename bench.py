@@ -298,8 +298,13 @@ def kernel_sections(np, torch, ops, model, eng, pset, batches, match_out, B, res
     cls, loc, mask = match_out
     t_fwd = timed(torch, lambda: eng.forward(x), 3)
     ploc, pconf = eng.forward(x)
-    _, dconf, dloc = ops.ssd_loss(pconf, ploc, cls, loc, mask)
-    t_bwd = timed(torch, lambda: eng.backward(dloc, dconf), 3)
+    hgb = eng.head_grad_buffers(B)              # the loss gradient as compact rows (None: dense head path selected)
+    if hgb is not None:
+        ops.ssd_loss_heads(pconf, ploc, cls, loc, mask, hgb)
+        t_bwd = timed(torch, lambda: eng.backward(None, None, heads=hgb), 3)
+    else:
+        _, dconf, dloc = ops.ssd_loss(pconf, ploc, cls, loc, mask)
+        t_bwd = timed(torch, lambda: eng.backward(dloc, dconf), 3)
     conv_flops = FLOP_TRAIN_PER_IMAGE * B
     conv_time = t_fwd + t_bwd
     # memory-side traffic of the convolution launches of one step, from rocprofv3 PMC passes (separate --pmc FETCH_SIZE /
@@ -329,11 +334,23 @@ def kernel_sections(np, torch, ops, model, eng, pset, batches, match_out, B, res
                                          floor_us_at_6300GBs=round(mbytes / 6.3e12 * 1e6, 2), batch_us=round(t_match * 1e6, 2))
 
     # ---- loss forward + backward (A6) on the network's bf16 logits of this batch ----
-    t_loss = graph_timed(torch, lambda: ops.ssd_loss(pconf, ploc, cls, loc, mask), 30)
     s = pconf.element_size()
-    lbytes = B * pset.A * (2 * 81 * s + 2 * 4 * s + 16 + 4 + 1)      # conf+loc in, dconf+dloc out, gloc f32x4, cls i32, mask u8
-    result["roofline_loss"] = hbm_entry("ssd_loss_fwd_bwd (k_loss_rows, k_loss_hist/select, k_loss_grad, k_loss_final)",
-                                        lbytes, t_loss, B, logits="bf16", batch_us=round(t_loss * 1e6, 2))
+    if hgb is not None:
+        # the form the step uses: the gradient leaves as compact rows (only the selected anchors are written), so the
+        # algorithmic bytes are one read of conf + loc and the targets; the dense form is timed beside it
+        t_loss = graph_timed(torch, lambda: ops.ssd_loss_heads(pconf, ploc, cls, loc, mask, hgb), 30)
+        t_dense = graph_timed(torch, lambda: ops.ssd_loss(pconf, ploc, cls, loc, mask), 30)
+        lbytes = B * pset.A * (81 * s + 4 * s + 16 + 4 + 1)
+        counts = hgb.count.cpu().tolist()[:hgb.levels]
+        result["roofline_loss"] = hbm_entry("ssd_loss_fwd_bwd_heads (k_loss_rows, k_loss_hist/select, k_hg_count/assign, k_loss_grad_rows, k_loss_final)",
+                                            lbytes, t_loss, B, logits="bf16", batch_us=round(t_loss * 1e6, 2),
+                                            dense_gradient_form_us=round(t_dense * 1e6, 2), gradient_rows_per_level=counts,
+                                            pixels_per_level=[B * h for h in hgb.hw])
+    else:
+        t_loss = graph_timed(torch, lambda: ops.ssd_loss(pconf, ploc, cls, loc, mask), 30)
+        lbytes = B * pset.A * (2 * 81 * s + 2 * 4 * s + 16 + 4 + 1)      # conf+loc in, dconf+dloc out, gloc f32x4, cls i32, mask u8
+        result["roofline_loss"] = hbm_entry("ssd_loss_fwd_bwd (k_loss_rows, k_loss_hist/select, k_loss_grad, k_loss_final)",
+                                            lbytes, t_loss, B, logits="bf16", batch_us=round(t_loss * 1e6, 2))
 
     # ---- inference post-processing (A9 + A9'): score + decode + per-class NMS on the SURVEY 8(d) NMS input ----
     result["roofline_detect"], m2_detect = detect_section(torch, ops, pset, B, torch.float32)
@@ -407,8 +424,13 @@ def cfg5_section(torch, ops, B):
         ops.match_encode(*gts, ps, 0.5, out=tgt)
         x = ops.image_prep(img, normalize=True)
         ploc, pconf = eng.forward(x)
-        _, dconf, dloc = ops.ssd_loss(pconf, ploc, *tgt)
-        eng.backward(dloc, dconf)
+        hg = eng.head_grad_buffers(Bs)
+        if hg is not None:
+            ops.ssd_loss_heads(pconf, ploc, *tgt, hg)
+            eng.backward(None, None, heads=hg)
+        else:
+            _, dconf, dloc = ops.ssd_loss(pconf, ploc, *tgt)
+            eng.backward(dloc, dconf)
         eng.clip_scales(0.01)
         eng.adam(1e-3, eng.grad, 1.0, True)
     t_step = timed(torch, step512, 5, warm=2)

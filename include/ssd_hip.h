@@ -145,6 +145,32 @@ int ssd_loss_fwd_bwd(const void* conf, const void* loc, int dtype, const int32_t
                      const float* gt_loc, const uint8_t* gt_mask, int B, int A, int C, float grad_scale,
                      float* out8, void* dconf, void* dloc, void* ws, size_t ws_bytes, void* stream);
 
+/* The same loss with the gradient handed over in the form the head convolutions' backward pass consumes, instead of the
+ * dense dconf / dloc.  Only the anchors the loss selects carry a gradient -- the positives and the mined negatives, 4P of
+ * B*A rows (:355-380; every other row of tape.gradient's result is exactly zero) -- so per feature level l the gradient is
+ * a COMPACT list of pixel rows: row r of level l is the head output gradient of pixel pixel_of_row[l][r] (flat index
+ * b*hw + y*W + x, ascending in r), channels in the head GEMM's order [per_cell*4 loc | per_cell*C conf | zero pad to npad];
+ * row_of_pixel[l][b*hw + pix] is the inverse map (-1: the pixel carries no gradient); count[l] rows are valid.  Scattered
+ * back, the rows are bit-identical to ssd_loss_fwd_bwd's dconf / dloc (tests/test_sparse_heads_gpu.py).
+ *   hg        HOST struct, device pointers inside; rows / maps sized for B*hw rows (every pixel selected)
+ *   dtype     SSD_BF16 only
+ *   ws        >= ssd_loss_heads_workspace_bytes(B, A, C) bytes
+ * Consumers: ssd_heads_bwd_data_sparse, ssd_heads_bwd_weight_sparse. */
+typedef struct {
+    int levels;                               /* <= SSD_MAX_LEVELS; sum of hw*per_cell over the levels == A          */
+    int hw[SSD_MAX_LEVELS];                   /* pixels of a level's feature map (H*W)                              */
+    int per_cell[SSD_MAX_LEVELS];             /* default boxes per pixel (:153)                                     */
+    int npad[SSD_MAX_LEVELS];                 /* row length, >= per_cell*(4+C), multiple of 8                       */
+    void* rows[SSD_MAX_LEVELS];               /* DEVICE bf16 [B*hw][npad]                                           */
+    int32_t* row_of_pixel[SSD_MAX_LEVELS];    /* DEVICE int32 [B*hw]                                                */
+    int32_t* pixel_of_row[SSD_MAX_LEVELS];    /* DEVICE int32 [B*hw]                                                */
+    int32_t* count;                           /* DEVICE int32 [SSD_MAX_LEVELS]                                      */
+} ssd_head_grads;
+size_t ssd_loss_heads_workspace_bytes(int B, int A, int C);
+int ssd_loss_fwd_bwd_heads(const void* conf, const void* loc, int dtype, const int32_t* gt_cls, const float* gt_loc,
+                           const uint8_t* gt_mask, int B, int A, int C, float grad_scale, float* out8,
+                           const ssd_head_grads* hg, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Inference scoring + decode -- replaces the scoring half of SSDObjectDetectionModel.visualize
  * (models/ssd_model.py:479-488, mask=None branch) and the box decode of visualize_dataset (:466-467).
@@ -271,6 +297,37 @@ int ssd_maxpool2x2_bwd(const void* x, const void* y, const void* dy, void* dx, i
 int ssd_maxpool2x2_fwd_argmax(const void* x, void* y, void* code, int B, int H, int W, int C, int Ho, int Wo, void* stream);
 int ssd_maxpool2x2_bwd_argmax(const void* code, const void* dy, void* dx, int B, int H, int W, int C, int Ho, int Wo,
                               void* stream);
+/* ------------------------------------------------------------------------------------------
+ * Backward pass of ALL head convolutions (models/ssd_model.py:153-162; 3x3, stride 1, SAME, no activation) from the compact
+ * gradient rows of ssd_loss_fwd_bwd_heads -- the part of tape.gradient (:248) behind the loc / conf outputs.  Work is
+ * proportional to the rows that carry a gradient (4P of B*A anchors), not to the feature maps; results equal the dense
+ * ssd_conv2d_bwd_data / ssd_conv2d_bwd_weight on the scattered rows up to fp32 summation order (dx rounds once to bf16).
+ * One launch sequence serves every level; row counts are read on the device (no host synchronisation); deterministic.
+ *   hl  HOST struct, per level: the feature map x bf16 [B,H,W,Cin] (Cin % 128 == 0 else SSD_ERR_UNSUPPORTED), cout =
+ *       per_cell*(4+C) filters, w_tap = the head filters transposed tap-major bf16 [3][3][Cin][npad] (w_tap[kh][kw][ci][co]
+ *       = w[co][kh][kw][ci], zero for co >= cout; ssd_weight_transpose_batched with bit 8 of the kernel-size field set),
+ *       the ReLU mask of x as sign bits (relu_bits, uint8 [B,H,W,Cin/8]) or as the activation itself (relu_src) or neither,
+ *       outputs dx bf16 [B,H,W,Cin] (overwritten: every pixel, zeros where no row reaches), dw f32 [cout][3][3][Cin], dbias
+ *       f32 [cout] or NULL.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int levels;
+    int H[SSD_MAX_LEVELS], W[SSD_MAX_LEVELS], Cin[SSD_MAX_LEVELS], cout[SSD_MAX_LEVELS];
+    const void* x[SSD_MAX_LEVELS];
+    const void* w_tap[SSD_MAX_LEVELS];
+    const void* relu_bits[SSD_MAX_LEVELS];
+    const void* relu_src[SSD_MAX_LEVELS];
+    void* dx[SSD_MAX_LEVELS];
+    float* dw[SSD_MAX_LEVELS];
+    float* dbias[SSD_MAX_LEVELS];
+} ssd_head_layers;
+size_t ssd_heads_bwd_data_sparse_workspace_bytes(int B, const ssd_head_layers* hl);
+int ssd_heads_bwd_data_sparse(const ssd_head_grads* hg, const ssd_head_layers* hl, int B, void* ws, size_t ws_bytes,
+                              void* stream);
+size_t ssd_heads_bwd_weight_sparse_workspace_bytes(int B, const ssd_head_grads* hg, const ssd_head_layers* hl);
+int ssd_heads_bwd_weight_sparse(const ssd_head_grads* hg, const ssd_head_layers* hl, int B, void* ws, size_t ws_bytes,
+                                void* stream);
+
 /* dloc[B,A,4], dconf[B,A,classes] (bf16) -> one level's padded NHWC head gradient [B, hw, npad] */
 int ssd_head_grad_pack(const void* dloc, const void* dconf, void* out, int B, int hw, int per_cell, int classes,
                        int npad, int anchors_total, int level_off, void* stream);

@@ -21,6 +21,37 @@ class PriorGrid(ctypes.Structure):
                 ("verified", ctypes.c_int)]
 
 
+class HeadGrads(ctypes.Structure):
+    """ssd_head_grads: the loss gradient as compact per-level pixel rows."""
+    _fields_ = [("levels", ctypes.c_int),
+                ("hw", ctypes.c_int * SSD_MAX_LEVELS),
+                ("per_cell", ctypes.c_int * SSD_MAX_LEVELS),
+                ("npad", ctypes.c_int * SSD_MAX_LEVELS),
+                ("rows", VP * SSD_MAX_LEVELS),
+                ("row_of_pixel", VP * SSD_MAX_LEVELS),
+                ("pixel_of_row", VP * SSD_MAX_LEVELS),
+                ("count", VP)]
+
+
+class HeadLayers(ctypes.Structure):
+    """ssd_head_layers: operands and outputs of the head convolutions' backward pass."""
+    _fields_ = [("levels", ctypes.c_int),
+                ("H", ctypes.c_int * SSD_MAX_LEVELS),
+                ("W", ctypes.c_int * SSD_MAX_LEVELS),
+                ("Cin", ctypes.c_int * SSD_MAX_LEVELS),
+                ("cout", ctypes.c_int * SSD_MAX_LEVELS),
+                ("x", VP * SSD_MAX_LEVELS),
+                ("w_tap", VP * SSD_MAX_LEVELS),
+                ("relu_bits", VP * SSD_MAX_LEVELS),
+                ("relu_src", VP * SSD_MAX_LEVELS),
+                ("dx", VP * SSD_MAX_LEVELS),
+                ("dw", VP * SSD_MAX_LEVELS),
+                ("dbias", VP * SSD_MAX_LEVELS)]
+
+
+_HG = ctypes.POINTER(HeadGrads)
+_HL = ctypes.POINTER(HeadLayers)
+
 _SIGNATURES = {
     "ssd_hip_abi_version": (ctypes.c_int, []),
     "ssd_status_string": (ctypes.c_char_p, [ctypes.c_int]),
@@ -75,6 +106,13 @@ _SIGNATURES = {
     "ssd_conv2d_bwd_weight_plan": (ctypes.c_int, [ctypes.c_int] * 12),
     "ssd_conv_plan_name": (ctypes.c_char_p, [ctypes.c_int]),
     "ssd_loss_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "ssd_loss_heads_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "ssd_loss_fwd_bwd_heads": (ctypes.c_int, [VP, VP, ctypes.c_int, VP, VP, VP, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_float, VP, _HG, VP, ctypes.c_size_t, VP]),
+    "ssd_heads_bwd_data_sparse_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, _HL]),
+    "ssd_heads_bwd_data_sparse": (ctypes.c_int, [_HG, _HL, ctypes.c_int, VP, ctypes.c_size_t, VP]),
+    "ssd_heads_bwd_weight_sparse_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, _HG, _HL]),
+    "ssd_heads_bwd_weight_sparse": (ctypes.c_int, [_HG, _HL, ctypes.c_int, VP, ctypes.c_size_t, VP]),
     "ssd_loss_fwd_bwd": (ctypes.c_int, [VP, VP, ctypes.c_int, VP, VP, VP, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_float, VP, VP, VP, VP, ctypes.c_size_t, VP]),
 }

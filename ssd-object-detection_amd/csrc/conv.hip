@@ -2683,7 +2683,9 @@ __global__ __launch_bounds__(256) void k_weight_transpose_batched(const long lon
     const long long* d = desc + (long long)blockIdx.y * 6;
     const bf16_raw* w = reinterpret_cast<const bf16_raw*>(d[0]);
     bf16_raw* wt = reinterpret_cast<bf16_raw*>(d[1]);
-    const int Cout = (int)d[2], K = (int)d[3], Cin = (int)d[4], Cout_pad = (int)d[5];
+    // K field: kernel size in the low byte; bit 8 set = tap-major layout for the sparse head data gradient (sparse.hip):
+    // wt[kh][kw][ci][co] = w[co][kh][kw][ci], not flipped
+    const int Cout = (int)d[2], K = (int)d[3] & 0xff, tapmajor = ((int)d[3] >> 8) & 1, Cin = (int)d[4], Cout_pad = (int)d[5];
     const int tco = (Cout_pad + 31) >> 5, tci = (Cin + 31) >> 5;
     int t = blockIdx.x;
     if (t >= tco * tci * K * K) return;
@@ -2695,14 +2697,17 @@ __global__ __launch_bounds__(256) void k_weight_transpose_batched(const long lon
     for (int j = 0; j < 4; ++j) {
         const int co = co0 + ty + 8 * j, ci = ci0 + tx;
         bf16_raw v = 0;
-        if (co < Cout && ci < Cin) v = w[(((long long)co * K + (K - 1 - kh)) * K + (K - 1 - kw)) * Cin + ci];
+        const int skh = tapmajor ? kh : K - 1 - kh, skw = tapmajor ? kw : K - 1 - kw;
+        if (co < Cout && ci < Cin) v = w[(((long long)co * K + skh) * K + skw) * Cin + ci];
         tile[ty + 8 * j][tx] = v;
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int ci = ci0 + ty + 8 * j, co = co0 + tx;
-        if (ci < Cin && co < Cout_pad) wt[(((long long)ci * K + kh) * K + kw) * Cout_pad + co] = tile[tx][ty + 8 * j];
+        if (ci >= Cin || co >= Cout_pad) continue;
+        if (tapmajor) wt[(((long long)kh * K + kw) * Cin + ci) * Cout_pad + co] = tile[tx][ty + 8 * j];
+        else wt[(((long long)ci * K + kh) * K + kw) * Cout_pad + co] = tile[tx][ty + 8 * j];
     }
 }
 

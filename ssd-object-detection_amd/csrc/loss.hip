@@ -419,12 +419,154 @@ __global__ __launch_bounds__(WG) void k_loss_final(size_t nblk, LossWs w, float*
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Gradient as compact per-level pixel rows (ssd_loss_fwd_bwd_heads).  An anchor carries a gradient iff it is a
+// positive or a mined negative (`selected`): ~4P of B*A rows.  Three launches behind the radix select:
+//   k_hg_count   (image, level): pixels with at least one selected anchor
+//   k_hg_assign  (image, level): rows in ascending pixel order (offset = counts of the images before: fixed, no
+//                atomics), both index maps, the rows zero-filled
+//   k_loss_grad_rows: the gradient of every selected anchor into its segment of its pixel's row
+struct HeadGradsDev {
+    int levels, A, B;
+    int hw[SSD_MAX_LEVELS], n[SSD_MAX_LEVELS], npad[SSD_MAX_LEVELS], off[SSD_MAX_LEVELS + 1];
+    __hip_bfloat16* rows[SSD_MAX_LEVELS];
+    int* rop[SSD_MAX_LEVELS];
+    int* por[SSD_MAX_LEVELS];
+    int* count;                              // [SSD_MAX_LEVELS]
+    int* img_count;                          // [levels][B] (workspace)
+};
+
+__device__ __forceinline__ bool hg_selected(const uint8_t* __restrict__ mask, const float* __restrict__ ce_bg, size_t g,
+                                            const Select& sel, float tau) {
+    return sel.ok && (mask[g] != 0 || ce_bg[g] >= tau);
+}
+
+__device__ __forceinline__ bool hg_pixel_flag(const HeadGradsDev& h, const uint8_t* __restrict__ mask, const LossWs& w,
+                                              int l, int b, int pix, const Select& sel, float tau) {
+    const size_t g0 = (size_t)b * h.A + h.off[l] + (size_t)pix * h.n[l];
+    bool f = false;
+    for (int a = 0; a < h.n[l]; ++a) f |= hg_selected(mask, w.ce_bg, g0 + a, sel, tau);
+    return f;
+}
+
+__device__ __forceinline__ int block_sum_int(int v, int* s4) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return s4[0] + s4[1] + s4[2] + s4[3];
+}
+
+__global__ __launch_bounds__(WG) void k_hg_count(const uint8_t* __restrict__ mask, LossWs w, HeadGradsDev h) {
+    __shared__ int s4[4];
+    const int b = blockIdx.x, l = blockIdx.y;
+    const Select sel = load_select(w);
+    const float tau = __uint_as_float(sel.tau_bits);
+    int c = 0;
+    for (int pix = threadIdx.x; pix < h.hw[l]; pix += WG) c += hg_pixel_flag(h, mask, w, l, b, pix, sel, tau) ? 1 : 0;
+    const int tot = block_sum_int(c, s4);
+    if (threadIdx.x == 0) h.img_count[l * h.B + b] = tot;
+}
+
+__global__ __launch_bounds__(WG) void k_hg_assign(const uint8_t* __restrict__ mask, LossWs w, HeadGradsDev h) {
+    __shared__ int s4[4];
+    __shared__ int s_wave[4];
+    const int b = blockIdx.x, l = blockIdx.y;
+    const Select sel = load_select(w);
+    const float tau = __uint_as_float(sel.tau_bits);
+    int before = 0;
+    for (int i = threadIdx.x; i < b; i += WG) before += h.img_count[l * h.B + i];
+    int base = block_sum_int(before, s4);                     // rows of this level in the images before this one
+    const int hw = h.hw[l], npad = h.npad[l];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int p0 = 0; p0 < hw; p0 += WG) {
+        const int pix = p0 + threadIdx.x;
+        const bool f = pix < hw && hg_pixel_flag(h, mask, w, l, b, pix, sel, tau);
+        const unsigned long long bal = __ballot(f);
+        __syncthreads();                                     // previous chunk's s_wave reads are done
+        if (lane == 0) s_wave[wave] = __popcll(bal);
+        __syncthreads();
+        int prefix = __popcll(bal & ((1ull << lane) - 1ull));
+        for (int k = 0; k < wave; ++k) prefix += s_wave[k];
+        const int chunk_total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        if (pix < hw) {
+            const int flat = b * hw + pix;
+            const int row = f ? base + prefix : -1;
+            h.rop[l][flat] = row;
+            if (f) {
+                h.por[l][row] = flat;
+                uint4* dst = reinterpret_cast<uint4*>(h.rows[l] + (size_t)row * npad);
+                for (int k = 0; k < npad / 8; ++k) dst[k] = make_uint4(0, 0, 0, 0);
+            }
+        }
+        base += chunk_total;
+    }
+    if (b == h.B - 1 && threadIdx.x == 0) h.count[l] = base;
+}
+
+// Gradient of the selected anchors only, written into the compact rows (the arithmetic of k_loss_grad).
+__global__ __launch_bounds__(WG) void k_loss_grad_rows(const __hip_bfloat16* __restrict__ conf, const __hip_bfloat16* __restrict__ loc,
+                                                       const int* __restrict__ cls, const float* __restrict__ gloc,
+                                                       const uint8_t* __restrict__ mask, size_t n, int C, float grad_scale,
+                                                       LossWs w, HeadGradsDev h) {
+    typedef __hip_bfloat16 T;
+    __shared__ double s_red[4];
+    const Select sel = load_select(w);
+    const size_t row0 = (size_t)blockIdx.x * ROWS;
+    const int nrow = (int)min((size_t)ROWS, n - row0);
+    const float tau = __uint_as_float(sel.tau_bits);
+    const float P = (float)w.counters[3];
+    const float inv_p = sel.ok ? grad_scale / P : 0.f;
+    const float inv_n = sel.ok && sel.n_neg > 0 ? grad_scale / (float)sel.n_neg : 0.f;
+    const int r = threadIdx.x >> 1, half = threadIdx.x & 1;
+    double acc_neg = 0.0;
+    if (r < nrow) {
+        const size_t g = row0 + r;
+        const bool pos = mask[g] != 0;
+        const float ce = w.ce_bg[g];
+        const bool neg = !pos && sel.ok && ce >= tau;
+        if (sel.ok && (pos || neg)) {
+            const int b = (int)(g / (size_t)h.A);
+            const int a = (int)(g - (size_t)b * h.A);
+            int l = 0;
+            for (int k = 1; k < h.levels; ++k) l += a >= h.off[k] ? 1 : 0;
+            const int idx = a - h.off[l];
+            const int pix = idx / h.n[l], slot = idx - pix * h.n[l];
+            const int row = h.rop[l][b * h.hw[l] + pix];
+            if (row >= 0) {
+                T* d = h.rows[l] + (size_t)row * h.npad[l];
+                const float lse = w.lse[g];
+                const float sc = pos ? inv_p : inv_n;
+                const int label = pos ? cls[g] : C - 1;
+                const T* z = conf + g * C;
+                T* o = d + h.n[l] * 4 + slot * C;
+                const int k0 = half ? (C + 1) / 2 : 0, k1 = half ? C : (C + 1) / 2;
+                for (int k = k0; k < k1; ++k) o[k] = from_f32<T>((__expf(to_f32<T>(z[k]) - lse) - (k == label ? 1.f : 0.f)) * sc);
+                if (pos && half == 0) {
+                    const float4 gl = reinterpret_cast<const float4*>(gloc)[g];
+                    const T* pl = loc + 4 * g;
+                    const float e0 = to_f32<T>(pl[0]) - gl.x, e1 = to_f32<T>(pl[1]) - gl.y;
+                    const float e2 = to_f32<T>(pl[2]) - gl.z, e3 = to_f32<T>(pl[3]) - gl.w;
+                    T* ol = d + slot * 4;
+                    ol[0] = from_f32<T>(e0 > 0.f ? inv_p : (e0 < 0.f ? -inv_p : 0.f));
+                    ol[1] = from_f32<T>(e1 > 0.f ? inv_p : (e1 < 0.f ? -inv_p : 0.f));
+                    ol[2] = from_f32<T>(e2 > 0.f ? inv_p : (e2 < 0.f ? -inv_p : 0.f));
+                    ol[3] = from_f32<T>(e3 > 0.f ? inv_p : (e3 < 0.f ? -inv_p : 0.f));
+                }
+            }
+            if (neg && half == 0) acc_neg = (double)ce;
+        }
+    }
+    const double bn = block_sum(acc_neg, s_red);
+    if (threadIdx.x == 0) w.part_neg[blockIdx.x] = bn;
+}
+
+// the launches both forms share: conf read once, exact radix select of tau
 template <typename T>
-int launch_loss(const void* conf, const void* loc, const int32_t* cls, const float* gloc, const uint8_t* mask,
-                size_t n, int C, float* out, void* dconf, void* dloc, float grad_scale, LossWs w, hipStream_t s) {
+void launch_loss_select(const void* conf, const void* loc, const int32_t* cls, const float* gloc, const uint8_t* mask,
+                        size_t n, int C, LossWs w, hipStream_t s, size_t lds) {
     const size_t nblk = (n + ROWS - 1) / ROWS;
-    const size_t lds = ((size_t)ROWS * C * sizeof(float) + 15) / 16 * 16;
-    if (hipMemsetAsync(w.hist1, 0, w.zero_bytes, s) != hipSuccess) return SSD_ERR_LAUNCH;
     const unsigned pgrid = (unsigned)min((size_t)MAX_PERSIST, nblk);
     if (C == 81)
         hipLaunchKernelGGL((k_loss_rows<T, 81>), dim3(pgrid), dim3(WG), lds, s, (const T*)conf, (const T*)loc, cls, gloc, mask, n, C, w);
@@ -435,6 +577,15 @@ int launch_loss(const void* conf, const void* loc, const int32_t* cls, const flo
     hipLaunchKernelGGL(k_loss_hist<2>, dim3(hgrid), dim3(WG), 0, s, n, w);
     hipLaunchKernelGGL(k_loss_hist<3>, dim3(hgrid), dim3(WG), 0, s, n, w);
     hipLaunchKernelGGL(k_loss_select, dim3(1), dim3(WG), 0, s, w);
+}
+
+template <typename T>
+int launch_loss(const void* conf, const void* loc, const int32_t* cls, const float* gloc, const uint8_t* mask,
+                size_t n, int C, float* out, void* dconf, void* dloc, float grad_scale, LossWs w, hipStream_t s) {
+    const size_t nblk = (n + ROWS - 1) / ROWS;
+    const size_t lds = ((size_t)ROWS * C * sizeof(float) + 15) / 16 * 16;
+    if (hipMemsetAsync(w.hist1, 0, w.zero_bytes, s) != hipSuccess) return SSD_ERR_LAUNCH;
+    launch_loss_select<T>(conf, loc, cls, gloc, mask, n, C, w, s, lds);
     hipLaunchKernelGGL(k_loss_grad<T>, dim3((unsigned)nblk), dim3(WG), lds, s, (const T*)conf, (const T*)loc, cls, gloc,
                        mask, n, C, grad_scale, (T*)dconf, (T*)dloc, w);
     hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(WG), 0, s, nblk, w, out);
@@ -448,6 +599,53 @@ extern "C" {
 size_t ssd_loss_workspace_bytes(int B, int A, int C) {
     if (B <= 0 || A <= 0 || C <= 0) return 0;
     return loss_ws_layout((size_t)B * A, nullptr, nullptr);
+}
+
+size_t ssd_loss_heads_workspace_bytes(int B, int A, int C) {
+    if (B <= 0 || A <= 0 || C <= 0) return 0;
+    return loss_ws_layout((size_t)B * A, nullptr, nullptr) + al256((size_t)SSD_MAX_LEVELS * B * sizeof(int));
+}
+
+int ssd_loss_fwd_bwd_heads(const void* conf, const void* loc, int dtype, const int32_t* gt_cls, const float* gt_loc,
+                           const uint8_t* gt_mask, int B, int A, int C, float grad_scale, float* out8,
+                           const ssd_head_grads* hg, void* ws, size_t ws_bytes, void* stream) {
+    if (B <= 0 || A <= 0 || C < 2 || !hg) return SSD_ERR_VALUE;
+    if (!conf || !loc || !gt_cls || !gt_loc || !gt_mask || !out8 || !hg->count) return SSD_ERR_VALUE;
+    if (dtype != SSD_BF16) return SSD_ERR_UNSUPPORTED;
+    if ((size_t)ROWS * C * sizeof(float) > 144 * 1024) return SSD_ERR_UNSUPPORTED;
+    if (hg->levels <= 0 || hg->levels > SSD_MAX_LEVELS) return SSD_ERR_VALUE;
+    HeadGradsDev h;
+    h.levels = hg->levels; h.A = A; h.B = B;
+    h.off[0] = 0;
+    for (int l = 0; l < hg->levels; ++l) {
+        if (hg->hw[l] <= 0 || hg->per_cell[l] <= 0 || hg->npad[l] < hg->per_cell[l] * (4 + C) || (hg->npad[l] & 7)) return SSD_ERR_VALUE;
+        if (!hg->rows[l] || !hg->row_of_pixel[l] || !hg->pixel_of_row[l]) return SSD_ERR_VALUE;
+        if ((long long)B * hg->hw[l] >= (1ll << 31)) return SSD_ERR_VALUE;
+        h.hw[l] = hg->hw[l]; h.n[l] = hg->per_cell[l]; h.npad[l] = hg->npad[l];
+        h.off[l + 1] = h.off[l] + hg->hw[l] * hg->per_cell[l];
+        h.rows[l] = (__hip_bfloat16*)hg->rows[l]; h.rop[l] = hg->row_of_pixel[l]; h.por[l] = hg->pixel_of_row[l];
+    }
+    for (int l = hg->levels; l < SSD_MAX_LEVELS; ++l) { h.hw[l] = h.n[l] = h.npad[l] = 0; h.off[l + 1] = h.off[l]; h.rows[l] = nullptr; h.rop[l] = h.por[l] = nullptr; }
+    if (h.off[hg->levels] != A) return SSD_ERR_ASSERT;            // models/ssd_model.py:350-351
+    h.count = hg->count;
+    const size_t n = (size_t)B * A;
+    const size_t base = loss_ws_layout(n, nullptr, nullptr);
+    if (!ws || ws_bytes < base + al256((size_t)SSD_MAX_LEVELS * B * sizeof(int))) return SSD_ERR_WORKSPACE;
+    LossWs w;
+    loss_ws_layout(n, static_cast<char*>(ws), &w);
+    h.img_count = reinterpret_cast<int*>(static_cast<char*>(ws) + base);
+    hipStream_t s = (hipStream_t)stream;
+    typedef __hip_bfloat16 T;
+    const size_t nblk = (n + ROWS - 1) / ROWS;
+    const size_t lds = ((size_t)ROWS * C * sizeof(float) + 15) / 16 * 16;
+    if (hipMemsetAsync(w.hist1, 0, w.zero_bytes, s) != hipSuccess) return SSD_ERR_LAUNCH;
+    launch_loss_select<T>(conf, loc, gt_cls, gt_loc, gt_mask, n, C, w, s, lds);
+    hipLaunchKernelGGL(k_hg_count, dim3(B, hg->levels), dim3(WG), 0, s, gt_mask, w, h);
+    hipLaunchKernelGGL(k_hg_assign, dim3(B, hg->levels), dim3(WG), 0, s, gt_mask, w, h);
+    hipLaunchKernelGGL(k_loss_grad_rows, dim3((unsigned)nblk), dim3(WG), 0, s, (const T*)conf, (const T*)loc, gt_cls, gt_loc,
+                       gt_mask, n, C, grad_scale, w, h);
+    hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(WG), 0, s, nblk, w, out8);
+    return ssd_launch_status();
 }
 
 int ssd_loss_fwd_bwd(const void* conf, const void* loc, int dtype, const int32_t* gt_cls, const float* gt_loc,

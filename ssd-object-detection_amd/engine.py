@@ -95,12 +95,17 @@ class SSDEngine:
         self.classes, self.in_size, self.device = classes, in_size, torch.device(device)
         self.trunk, self.num_priors = list(trunk), tuple(num_priors)
         self.block = self.L.ssd_opt_block_elems()
+        # the heads' backward pass from the loss's compact gradient rows (csrc/sparse.hip); SSD_SPARSE_HEADS=0: the dense
+        # kernels on the scattered gradient (tests compare the two)
+        self.sparse_heads = os.environ.get("SSD_SPARSE_HEADS", "1") == "1"
         self._plan_shapes()
         self._plan_params()
         self._alloc_params()
         self.init_params(seed)
         self._act_cache = {}
         self._ws = ops.MatchWorkspace()
+        self._ws_hz = ops.MatchWorkspace()     # Z of the sparse head data gradient
+        self._ws_hw = ops.MatchWorkspace()     # slabs of the sparse head weight gradient
         self._side = None
         self.overlap_heads = os.environ.get("SSD_OVERLAP_HEADS", "1") != "0" and self.device.type == "cuda"
         self.step_count = 0
@@ -128,6 +133,8 @@ class SSDEngine:
             if feat:
                 self.fm.append((len(self.nodes) - 1, ho, cout))
         assert len(self.fm) == len(self.num_priors)
+        if any(c % 128 for _, _, c in self.fm) or len(self.fm) > _lib.SSD_MAX_LEVELS:
+            self.sparse_heads = False
         self.level_off = [0]
         for (_, h, _), n in zip(self.fm, self.num_priors):
             self.level_off.append(self.level_off[-1] + h * h * n)
@@ -192,7 +199,9 @@ class SSDEngine:
             if nd["kind"] == "conv" and i > 0:
                 self.w_t[i] = torch.empty((nd["cin"], nd["k"], nd["k"], nd["cout"]), dtype=torch.bfloat16, device=dev)
         self.head_npad = [(n * (4 + self.classes) + 7) // 8 * 8 for n in self.num_priors]
-        self.head_w_t = [torch.empty((c, 3, 3, npad), dtype=torch.bfloat16, device=dev)
+        # transposed head filters: [Cin][3][3][npad] flipped for the dense data gradient, or tap-major [3][3][Cin][npad] for
+        # the sparse one
+        self.head_w_t = [torch.empty((3, 3, c, npad) if self.sparse_heads else (c, 3, 3, npad), dtype=torch.bfloat16, device=dev)
                          for (_, _, c), npad in zip(self.fm, self.head_npad)]
 
     # ---------------------------------------------------------------- parameter views
@@ -232,11 +241,13 @@ class SSDEngine:
         if getattr(self, "_tr_desc", None) is None:         # {src, dst, Cout, k, Cin, Cout_pad} per transposed copy
             rows, tiles = [], 0
             pairs = [(self.conv_params[i][0], wt) for i, wt in self.w_t.items()]
+            n_trunk = len(pairs)
             pairs += [(self.head_params[lvl][0], wt) for lvl, wt in enumerate(self.head_w_t)]
-            for pt, wt in pairs:
+            for r, (pt, wt) in enumerate(pairs):
                 cout, k, _, cin = pt.shape
                 cpad = wt.shape[-1]
-                rows.append([self.view(pt, self.param_bf16).data_ptr(), wt.data_ptr(), cout, k, cin, cpad])
+                kfield = k | (0x100 if (self.sparse_heads and r >= n_trunk) else 0)     # bit 8: tap-major, not flipped
+                rows.append([self.view(pt, self.param_bf16).data_ptr(), wt.data_ptr(), cout, kfield, cin, cpad])
                 tiles = max(tiles, ((cpad + 31) // 32) * ((cin + 31) // 32) * k * k)
             self._tr_desc = torch.tensor(rows, dtype=torch.int64, device=self.device)
             self._tr_tiles = tiles
@@ -272,7 +283,10 @@ class SSDEngine:
             # instead of the bf16 activation
             rbits = {i + 1: torch.empty((B, nd["hout"], nd["hout"], nd["cout"] // 8), dtype=torch.uint8, device=dev)
                      for i, nd in enumerate(self.nodes) if nd["kind"] == "conv" and nd["cout"] % 8 == 0}
-            c = dict(acts=acts, gacts=gacts, loc=loc, conf=conf, packed=packed, pool_code=pool_code, rbits=rbits)
+            hgb = None
+            if self.sparse_heads:
+                hgb = ops.HeadGradBuffers(B, [h * h for _, h, _ in self.fm], self.num_priors, self.head_npad, device=dev)
+            c = dict(acts=acts, gacts=gacts, loc=loc, conf=conf, packed=packed, pool_code=pool_code, rbits=rbits, hgb=hgb)
             self._act_cache = {B: c}              # keep one batch size resident
         return c
 
@@ -373,7 +387,43 @@ class SSDEngine:
                 main.wait_stream(tail)
         return c["loc"], c["conf"]
 
-    def backward(self, dloc, dconf, on_ready=None, fused_adam=None):
+    def head_grad_buffers(self, B):
+        """The ops.HeadGradBuffers the loss writes for a batch of B (None when the dense head path is selected)."""
+        return self._acts(B)["hgb"]
+
+    def heads_from_dense(self, dloc, dconf):
+        """Compact rows from a dense (dloc, dconf) pair -- for callers that hold an arbitrary gradient (tests, the oracle
+        comparison); the training step gets the rows from the loss directly.  Synchronises the host."""
+        B = dloc.shape[0]
+        hgb = self.head_grad_buffers(B)
+        counts = []
+        for lvl, (_, h, _) in enumerate(self.fm):
+            npad = self.head_npad[lvl]
+            packed = ops.head_grad_pack(dloc, dconf, h * h, self.num_priors[lvl], self.classes, npad,
+                                        self.level_off[lvl]).view(B * h * h, npad)
+            idx = (packed != 0).any(dim=1).nonzero().squeeze(1)
+            k = int(idx.numel())
+            hgb.rows[lvl][:k] = packed[idx]
+            hgb.pixel_of_row[lvl][:k] = idx.int()
+            hgb.row_of_pixel[lvl].fill_(-1)
+            hgb.row_of_pixel[lvl][idx] = torch.arange(k, dtype=torch.int32, device=idx.device)
+            counts.append(k)
+        hgb.count[:len(counts)] = torch.tensor(counts, dtype=torch.int32, device=hgb.count.device)
+        return hgb
+
+    def _head_layers(self, c):
+        acts, gacts = c["acts"], c["gacts"]
+        idx = [ni + 1 for ni, _, _ in self.fm]
+        use_bits = [self.relu_bits is not None and a in self.bits_valid for a in idx]
+        hl, keep = ops.head_layers(
+            [acts[a] for a in idx], self.head_w_t, [gacts[a] for a in idx],
+            [self.view(wt, self.grad) for wt, _ in self.head_params], [self.view(bt, self.grad) for _, bt in self.head_params],
+            [n * (4 + self.classes) for n in self.num_priors],
+            relu_bits=[c["rbits"][a] if ub else None for a, ub in zip(idx, use_bits)],
+            relu_src=[None if ub else acts[a] for a, ub in zip(idx, use_bits)])
+        return hl, keep
+
+    def backward(self, dloc, dconf, on_ready=None, fused_adam=None, heads=None):
         """Gradients of all parameters into self.grad (flat fp32) from d(loss)/d(loc), d(loss)/d(conf).
         on_ready([tensor indices]) is called right after the launches that complete those tensors' gradients (on the
         stream that runs them: an event recorded there covers them).
@@ -384,7 +434,9 @@ class SSDEngine:
         The data-gradient chain (the critical path) runs on the current stream, every weight gradient on the side
         stream as soon as its input gradient exists: the split reductions and round tails of one overlap the MFMA
         work of the other.  Each launch still sums in a fixed order, so results do not depend on the overlap."""
-        B = dloc.shape[0]
+        if heads is None and self.sparse_heads:
+            heads = self.heads_from_dense(dloc, dconf)
+        B = heads.B if heads is not None else dloc.shape[0]
         c = self._acts(B)
         acts, gacts = c["acts"], c["gacts"]
         written = [False] * len(acts)
@@ -423,7 +475,17 @@ class SSDEngine:
         # that the main stream can walk the small levels and the extras' data-gradient chain (a dozen launches that
         # each fill a fraction of the chip) underneath them.  The accumulation order into a feature-map gradient is
         # still "head first, trunk second": the trunk launch waits for the head's event.
-        big = [lvl for lvl, (ni, h, ch) in enumerate(self.fm) if side is not None and B * h * h >= 16384
+        if heads is not None:
+            # all levels at once from the compact rows: data gradient on the main stream (every feature-map gradient is
+            # written before the trunk chain accumulates into it), weight gradient next to it on the side stream
+            hl, keep = self._head_layers(c)
+            on_side(lambda ws: ops.heads_bwd_weight_sparse(heads, hl, ws=self._ws_hw),
+                    [i for wt, bt in self.head_params for t in (wt, bt) for i in t.indices])
+            ops.heads_bwd_data_sparse(heads, hl, ws=self._ws_hz)
+            for ni, _, _ in self.fm:
+                written[ni + 1] = True
+            del keep
+        big = [lvl for lvl, (ni, h, ch) in enumerate(self.fm) if heads is None and side is not None and B * h * h >= 16384
                and os.environ.get("SSD_BIG_HEADS_SIDE", "1") == "1"]
         head_done = {}                                     # activation index -> event after the head's data gradient
         packed = [None] * len(self.fm)
@@ -434,7 +496,7 @@ class SSDEngine:
                                              self.level_off[lvl], out=c["packed"][lvl]).view(B, h, h, self.head_npad[lvl])
 
         pack_side = os.environ.get("SSD_PACK_SIDE", "1") == "1"
-        for lvl in range(len(self.fm)):                    # the large levels are packed where they are consumed (side stream)
+        for lvl in range(len(self.fm) if heads is None else 0):   # the large levels are packed where they are consumed (side stream)
             if lvl not in big or not pack_side:
                 pack(lvl)
 
@@ -478,7 +540,7 @@ class SSDEngine:
                     head_wgrad(lvl, self._ws_side)
                     if on_ready:
                         on_ready([i for t in self.head_params[lvl] for i in t.indices])
-        for lvl in range(len(self.fm)):
+        for lvl in range(len(self.fm) if heads is None else 0):
             if lvl in big:
                 continue
             on_side(lambda ws, lvl=lvl: head_wgrad(lvl, ws), [i for t in self.head_params[lvl] for i in t.indices])

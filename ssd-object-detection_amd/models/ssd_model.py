@@ -177,15 +177,20 @@ class SSDObjectDetectionModel:
 
     # ------------------------------------------------------------------ loss (A6)
     @staticmethod
-    def _ssd_loss(y_true, y_pred):
+    def _ssd_loss(y_true, y_pred, heads=None):
         """Returns (total loss tensor, info) where info maps the reference's three names to device scalars and
-        carries the gradients w.r.t. (pred_box, pred_cls) under 'dloc' / 'dconf'."""
+        carries the gradients w.r.t. (pred_box, pred_cls) under 'dloc' / 'dconf' -- or, with `heads` (the engine's
+        ops.HeadGradBuffers), as the compact per-level rows the heads' backward pass consumes ('heads')."""
         gt_cls, gt_box, gt_mask = y_true
         pred_box, pred_cls = y_pred
         assert gt_cls.shape[0] == gt_box.shape[0] == gt_mask.shape[0] == pred_box.shape[0] == pred_cls.shape[0]
-        out, dconf, dloc = ops.ssd_loss(pred_cls, pred_box, gt_cls, gt_box, gt_mask)
+        if heads is not None:
+            out = ops.ssd_loss_heads(pred_cls, pred_box, gt_cls, gt_box, gt_mask, heads)
+            dconf = dloc = None
+        else:
+            out, dconf, dloc = ops.ssd_loss(pred_cls, pred_box, gt_cls, gt_box, gt_mask)
         info = {"cls loss pos": out[1], "cls loss neg": out[2], "loc loss": out[0], "status": out[7],
-                "dconf": dconf, "dloc": dloc, "raw": out}
+                "dconf": dconf, "dloc": dloc, "heads": heads, "raw": out}
         return out[3], info
 
     # ------------------------------------------------------------------ train step (A7)
@@ -222,11 +227,12 @@ class SSDObjectDetectionModel:
             if self._targets_event is not None:        # targets assigned on the side stream (match_async)
                 torch.cuda.current_stream().wait_event(self._targets_event)
                 self._targets_event = None
+            heads = eng.head_grad_buffers(pred_loc.shape[0]) if pred_conf.dtype == torch.bfloat16 else None
             _, info = self._ssd_loss((gt_cls[i:i + batch_step], gt_bbox[i:i + batch_step], gt_mask[i:i + batch_step]),
-                                     (pred_loc, pred_conf))
+                                     (pred_loc, pred_conf), heads)
             if overlap:
                 self._reducer.begin()
-                eng.backward(info["dloc"], info["dconf"], on_ready=self._reducer.tensor_ready)
+                eng.backward(info["dloc"], info["dconf"], on_ready=self._reducer.tensor_ready, heads=info["heads"])
                 post = None
                 if fused_dp:                           # Adam of a bucket right behind its all-reduce, on the comm stream
                     eng.step_count = ssd_optimizer.iterations + 1
@@ -237,9 +243,9 @@ class SSDObjectDetectionModel:
                     post = lambda t0, t1: eng.adam_range(t0, t1, lr_t, b1, b2, ssd_optimizer.epsilon, None, 1.0 / world)
                 self._reducer.finish(post)             # clipped per bucket, summed over ranks (RCCL over xGMI)
             elif fused:
-                eng.backward(info["dloc"], info["dconf"], fused_adam=fused_adam)
+                eng.backward(info["dloc"], info["dconf"], fused_adam=fused_adam, heads=info["heads"])
             else:
-                eng.backward(info["dloc"], info["dconf"])
+                eng.backward(info["dloc"], info["dconf"], heads=info["heads"])
                 eng.clip_scales(0.01)                  # tf.clip_by_norm(x, 0.01) per tensor, reference :249
                 if not single:
                     eng.accumulate_clipped(first=(n_micro == 0))

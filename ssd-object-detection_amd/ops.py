@@ -194,6 +194,114 @@ def ssd_loss(conf, loc, gt_cls, gt_loc, gt_mask, grad_scale=1.0, ws=None):
     return out, dconf, dloc
 
 
+class HeadGradBuffers:
+    """Device buffers behind an ssd_head_grads: per level the compact gradient rows [B*hw, npad] bf16, both index maps
+    and the row counts.  `hw`, `per_cell`, `npad` are per-level lists; sum(hw*per_cell) == A."""
+
+    def __init__(self, B, hw, per_cell, npad, device="cuda"):
+        self.B, self.hw, self.per_cell, self.npad = B, list(hw), list(per_cell), list(npad)
+        self.levels = len(self.hw)
+        assert self.levels <= _lib.SSD_MAX_LEVELS
+        self.rows = [torch.empty((B * h, p), dtype=torch.bfloat16, device=device) for h, p in zip(self.hw, self.npad)]
+        self.row_of_pixel = [torch.empty((B * h,), dtype=torch.int32, device=device) for h in self.hw]
+        self.pixel_of_row = [torch.empty((B * h,), dtype=torch.int32, device=device) for h in self.hw]
+        self.count = torch.zeros((_lib.SSD_MAX_LEVELS,), dtype=torch.int32, device=device)
+        c = _lib.HeadGrads()
+        c.levels = self.levels
+        for l in range(self.levels):
+            c.hw[l], c.per_cell[l], c.npad[l] = self.hw[l], self.per_cell[l], self.npad[l]
+            c.rows[l], c.row_of_pixel[l], c.pixel_of_row[l] = (self.rows[l].data_ptr(), self.row_of_pixel[l].data_ptr(),
+                                                               self.pixel_of_row[l].data_ptr())
+        c.count = self.count.data_ptr()
+        self.c = c
+
+    def dense(self, classes):
+        """(dloc [B,A,4], dconf [B,A,classes]) scattered back from the rows (tests; one host sync)."""
+        B = self.B
+        counts = self.count.cpu().tolist()
+        locs, confs = [], []
+        for l in range(self.levels):
+            h, n, p = self.hw[l], self.per_cell[l], self.npad[l]
+            full = torch.zeros((B * h, p), dtype=torch.bfloat16, device=self.rows[l].device)
+            k = counts[l]
+            full[self.pixel_of_row[l][:k].long()] = self.rows[l][:k]
+            locs.append(full[:, :n * 4].reshape(B, h * n, 4))
+            confs.append(full[:, n * 4:n * (4 + classes)].reshape(B, h * n, classes))
+        return torch.cat(locs, 1), torch.cat(confs, 1)
+
+
+def ssd_loss_heads(conf, loc, gt_cls, gt_loc, gt_mask, hgb, grad_scale=1.0, ws=None):
+    """ssd_loss_fwd_bwd_heads: the loss of ssd_loss with its gradient as compact per-level pixel rows in `hgb`
+    (HeadGradBuffers).  Returns out8 (device f32[8])."""
+    L = _lib.lib()
+    B, A, C = conf.shape
+    assert conf.dtype == loc.dtype == torch.bfloat16 and conf.is_cuda and conf.is_contiguous() and loc.is_contiguous()
+    assert loc.shape == (B, A, 4) and gt_loc.shape == (B, A, 4)          # models/ssd_model.py:347-351
+    assert gt_cls.shape == (B, A) and gt_mask.shape == (B, A) and hgb.B == B
+    _dev(gt_cls, torch.int32); _dev(gt_loc, torch.float32); _dev(gt_mask, torch.uint8)
+    out = torch.empty((8,), dtype=torch.float32, device=conf.device)
+    nbytes = L.ssd_loss_heads_workspace_bytes(B, A, C)
+    wbuf = (ws or _loss_ws).get(nbytes, conf.device)
+    _lib.check(L.ssd_loss_fwd_bwd_heads(_ptr(conf), _ptr(loc), 1, _ptr(gt_cls), _ptr(gt_loc), _ptr(gt_mask), B, A, C,
+                                        float(grad_scale), _ptr(out), ctypes.byref(hgb.c), _ptr(wbuf), wbuf.numel(),
+                                        _stream()))
+    return out
+
+
+def head_layers(x, w_tap, dx, dw, dbias, cout, relu_bits=None, relu_src=None):
+    """ssd_head_layers from per-level lists of tensors (x bf16 [B,H,W,Cin]; w_tap bf16 [3,3,Cin,npad]; dx like x; dw f32
+    [cout,3,3,Cin]; dbias f32 [cout] or None).  Returns (struct, keep-alive list)."""
+    c = _lib.HeadLayers()
+    c.levels = len(x)
+    keep = []
+    for l, xl in enumerate(x):
+        _bf(xl); _bf(w_tap[l]); _bf(dx[l])
+        _, H, W, Cin = xl.shape
+        assert w_tap[l].shape[:3] == (3, 3, Cin) and dx[l].shape == xl.shape and dw[l].is_contiguous()
+        c.H[l], c.W[l], c.Cin[l], c.cout[l] = H, W, Cin, cout[l]
+        c.x[l], c.w_tap[l], c.dx[l], c.dw[l] = xl.data_ptr(), w_tap[l].data_ptr(), dx[l].data_ptr(), dw[l].data_ptr()
+        c.dbias[l] = dbias[l].data_ptr() if dbias is not None and dbias[l] is not None else None
+        rb = relu_bits[l] if relu_bits is not None else None
+        rs = relu_src[l] if relu_src is not None else None
+        c.relu_bits[l] = rb.data_ptr() if rb is not None else None
+        c.relu_src[l] = rs.data_ptr() if rs is not None else None
+        keep += [xl, w_tap[l], dx[l], dw[l], rb, rs]
+    return c, keep
+
+
+_heads_z_ws = MatchWorkspace()
+_heads_w_ws = MatchWorkspace()
+
+
+def heads_bwd_data_sparse(hgb, hl, ws=None):
+    L = _lib.lib()
+    nbytes = L.ssd_heads_bwd_data_sparse_workspace_bytes(hgb.B, ctypes.byref(hl))
+    wbuf = (ws or _heads_z_ws).get(nbytes, hgb.count.device)
+    _lib.check(L.ssd_heads_bwd_data_sparse(ctypes.byref(hgb.c), ctypes.byref(hl), hgb.B, _ptr(wbuf), wbuf.numel(), _stream()))
+
+
+def heads_bwd_weight_sparse(hgb, hl, ws=None):
+    L = _lib.lib()
+    nbytes = L.ssd_heads_bwd_weight_sparse_workspace_bytes(hgb.B, ctypes.byref(hgb.c), ctypes.byref(hl))
+    wbuf = (ws or _heads_w_ws).get(nbytes, hgb.count.device)
+    _lib.check(L.ssd_heads_bwd_weight_sparse(ctypes.byref(hgb.c), ctypes.byref(hl), hgb.B, _ptr(wbuf), wbuf.numel(), _stream()))
+
+
+def weight_transpose_tap(w, cout_pad=None, out=None):
+    """w bf16 [Cout,3,3,Cin] -> tap-major transposed copy [3,3,Cin,Cout_pad] (not flipped): the operand of the sparse head
+    data gradient.  One-tensor call of ssd_weight_transpose_batched."""
+    L = _lib.lib()
+    _bf(w)
+    Cout, k, _, Cin = w.shape
+    cout_pad = cout_pad or (Cout + 7) // 8 * 8
+    if out is None:
+        out = torch.empty((k, k, Cin, cout_pad), dtype=torch.bfloat16, device=w.device)
+    desc = torch.tensor([[w.data_ptr(), out.data_ptr(), Cout, k | 0x100, Cin, cout_pad]], dtype=torch.int64, device=w.device)
+    tiles = ((cout_pad + 31) // 32) * ((Cin + 31) // 32) * k * k
+    _lib.check(L.ssd_weight_transpose_batched(_ptr(desc), 1, tiles, _stream()))
+    return out
+
+
 def score_decode(conf, loc, pset, score_thresh=0.5, in_size=300.0):
     """ssd_score_decode (replaces visualize's scoring, models/ssd_model.py:479-488, + decode :466-467).
     Returns (score f32[B,A], cls i32[B,A], box f32[B,A,4] pixels, cand u8[B,A])."""

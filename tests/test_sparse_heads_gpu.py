@@ -1,0 +1,210 @@
+"""GPU parity of the sparse head backward path (csrc/sparse.hip, ssd_loss_fwd_bwd_heads).
+
+The loss hands the heads only the pixel rows that carry a gradient (positives + mined negatives,
+models/ssd_model.py:355-380).  Checked here:
+  * the compact rows scattered back equal ssd_loss_fwd_bwd's dense dconf / dloc BIT FOR BIT, the loss scalars too;
+    both index maps are consistent and ascending;
+  * ssd_heads_bwd_data_sparse / _weight_sparse against the plain PyTorch fp32 restatement of the 3x3 head convolution's
+    gradients (oracle: torch conv2d autograd on the CPU) -- dx within 2^-7 of the tensor maximum (one bf16 rounding), dw /
+    dbias within 1e-3 (fp32 accumulation order) -- and against the dense kernels on the scattered rows;
+  * a level without any selected anchor (count 0) yields exact zeros; all-equal logits (every anchor selected: 100 %
+    density) still agree with the dense path;
+  * bitwise determinism of repeated runs.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+import torch.nn.functional as F                                      # noqa: E402
+
+HW = (1444, 361, 100, 25, 9, 1)
+SIDE = (38, 19, 10, 5, 3, 1)
+NPC = (4, 6, 6, 6, 4, 4)
+CIN = (512, 1024, 512, 256, 256, 256)
+NPAD = tuple((n * 85 + 7) // 8 * 8 for n in NPC)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import ssd_object_detection_amd.ops as ops_
+    return ops_
+
+
+def make_targets(ops, B, first=0, n_t=None):
+    from ssd_object_detection_amd.data_loaders.synthetic import synth_batch_gt
+    pset = ops.build_priors()
+    cls_l, box_l = synth_batch_gt(first, B, n_t)
+    gt_box, gt_cls, gt_off, total, max_nt = ops.pack_gt(box_l, cls_l)
+    return ops.match_encode(gt_box, gt_cls, gt_off, total, max_nt, pset, 0.5)
+
+
+def logits(B, seed, bg=0.0, scale=1.0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    conf = scale * torch.randn((B, 8732, 81), generator=g, device="cuda")
+    conf[..., 80] += bg
+    loc = 0.5 * torch.randn((B, 8732, 4), generator=g, device="cuda")
+    return conf.bfloat16().contiguous(), loc.bfloat16().contiguous()
+
+
+def check_maps(hgb):
+    counts = hgb.count.cpu().tolist()
+    for l in range(hgb.levels):
+        k = counts[l]
+        por = hgb.pixel_of_row[l][:k].cpu().numpy()
+        rop = hgb.row_of_pixel[l].cpu().numpy()
+        assert np.all(np.diff(por) > 0), "rows are not in ascending pixel order"
+        assert np.array_equal(rop[por], np.arange(k)), "row_of_pixel is not the inverse of pixel_of_row"
+        assert (rop >= 0).sum() == k and rop.min() >= -1
+    return counts
+
+
+@pytest.mark.parametrize("B,bg", [(4, 0.0), (3, 3.0), (1, 0.0)])
+def test_rows_equal_the_dense_gradient(ops, B, bg):
+    cls, gloc, mask = make_targets(ops, B, first=10 * B)
+    conf, loc = logits(B, 3 + B, bg)
+    out_d, dconf, dloc = ops.ssd_loss(conf, loc, cls, gloc, mask)
+    hgb = ops.HeadGradBuffers(B, HW, NPC, NPAD)
+    out_s = ops.ssd_loss_heads(conf, loc, cls, gloc, mask, hgb)
+    assert torch.equal(out_d, out_s), (out_d, out_s)
+    assert float(out_s[7]) == 0.0
+    counts = check_maps(hgb)
+    sl, sc = hgb.dense(81)
+    assert torch.equal(sl.view(torch.int16), dloc.view(torch.int16))
+    assert torch.equal(sc.view(torch.int16), dconf.view(torch.int16))
+    # exactly the pixels with a selected anchor were given a row
+    nz = (dconf != 0).any(-1) | (dloc != 0).any(-1)
+    off = 0
+    for l in range(6):
+        a = nz[:, off:off + HW[l] * NPC[l]].reshape(B, HW[l], NPC[l]).any(-1)
+        # (a selected anchor whose gradient rounds to all zeros would still own a row: allow >=)
+        assert counts[l] >= int(a.sum())
+        assert counts[l] <= int(a.sum()) + 2
+        off += HW[l] * NPC[l]
+    # padding columns of the rows are zero
+    for l in range(6):
+        k = counts[l]
+        assert not bool((hgb.rows[l][:k, NPC[l] * 85:] != 0).any())
+
+
+def test_status_codes_leave_no_rows(ops):
+    """P == 0 (status 1): no anchor is selected, every level has zero rows."""
+    B = 2
+    cls = torch.zeros((B, 8732), dtype=torch.int32, device="cuda")
+    gloc = torch.zeros((B, 8732, 4), dtype=torch.float32, device="cuda")
+    mask = torch.zeros((B, 8732), dtype=torch.uint8, device="cuda")
+    conf, loc = logits(B, 1)
+    hgb = ops.HeadGradBuffers(B, HW, NPC, NPAD)
+    out = ops.ssd_loss_heads(conf, loc, cls, gloc, mask, hgb)
+    assert float(out[7]) == 1.0
+    assert hgb.count.cpu().tolist()[:6] == [0] * 6
+
+
+def head_oracle(x, w, rows_dense):
+    """fp32 gradients of y = conv3x3_same(x, w) + b for dL/dy = rows_dense, on the CPU.  x [B,H,W,Cin], w [cout,3,3,Cin],
+    rows_dense [B,H,W,cout] (all float32)."""
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    wr = w.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    br = torch.zeros(w.shape[0], requires_grad=True)
+    y = F.conv2d(xr, wr, br, padding=1)
+    y.backward(rows_dense.permute(0, 3, 1, 2))
+    return xr.grad.permute(0, 2, 3, 1), wr.grad.permute(0, 2, 3, 1), br.grad
+
+
+def run_heads(ops, B, conf, loc, targets, seed=0, levels=range(6), check_oracle=(0, 1, 2, 3, 4, 5), use_bits=True):
+    cls, gloc, mask = targets
+    hgb = ops.HeadGradBuffers(B, HW, NPC, NPAD)
+    ops.ssd_loss_heads(conf, loc, cls, gloc, mask, hgb)
+    counts = hgb.count.cpu().tolist()
+    g = torch.Generator(device="cuda").manual_seed(100 + seed)
+    xs, ws, wts, dxs, dws, dbs, bits = [], [], [], [], [], [], []
+    for l in range(6):
+        x = torch.randn((B, SIDE[l], SIDE[l], CIN[l]), generator=g, device="cuda").clamp_min(0).bfloat16().contiguous()
+        w = (0.05 * torch.randn((NPC[l] * 85, 3, 3, CIN[l]), generator=g, device="cuda")).bfloat16().contiguous()
+        xs.append(x); ws.append(w)
+        wts.append(ops.weight_transpose_tap(w, NPAD[l]))
+        dxs.append(torch.full_like(x, 7.0))                 # must be overwritten everywhere
+        dws.append(torch.full(w.shape, 7.0, dtype=torch.float32, device="cuda"))
+        dbs.append(torch.full((w.shape[0],), 7.0, dtype=torch.float32, device="cuda"))
+        b8 = (x > 0).view(B, SIDE[l], SIDE[l], CIN[l] // 8, 8).to(torch.uint8)
+        bits.append((b8 * (2 ** torch.arange(8, device="cuda", dtype=torch.uint8))).sum(-1).to(torch.uint8).contiguous())
+    hl, keep = ops.head_layers(xs, wts, dxs, dws, dbs, [n * 85 for n in NPC],
+                               relu_bits=bits if use_bits else None, relu_src=None if use_bits else xs)
+    ops.heads_bwd_data_sparse(hgb, hl)
+    ops.heads_bwd_weight_sparse(hgb, hl)
+    torch.cuda.synchronize()
+    sl, sc = hgb.dense(81)
+    for l in levels:
+        n, h, s = NPC[l], HW[l], SIDE[l]
+        off = sum(HW[k] * NPC[k] for k in range(l))
+        dl = sl[:, off:off + h * n].reshape(B, h, n * 4)
+        dc = sc[:, off:off + h * n].reshape(B, h, n * 81)
+        dy = torch.cat([dl, dc], -1).reshape(B, s, s, n * 85).float().cpu()
+        if counts[l] == 0:
+            assert not bool((dxs[l] != 0).any()) and not bool((dws[l] != 0).any()) and not bool((dbs[l] != 0).any())
+            continue
+        if l in check_oracle:
+            rdx, rdw, rdb = head_oracle(xs[l].float().cpu(), ws[l].float().cpu(), dy)
+            rdx = rdx * (xs[l].float().cpu() > 0)
+            got = dxs[l].float().cpu()
+            assert (got - rdx).abs().max() <= 2.0 ** -7 * rdx.abs().max() + 1e-12, (l, (got - rdx).abs().max(), rdx.abs().max())
+            gw = dws[l].cpu()
+            assert (gw - rdw).abs().max() <= 1e-3 * rdw.abs().max() + 1e-12, (l, (gw - rdw).abs().max(), rdw.abs().max())
+            assert (dbs[l].cpu() - rdb).abs().max() <= 1e-3 * rdb.abs().max() + 1e-12
+    return hgb, dxs, dws, dbs, xs, ws, (sl, sc)
+
+
+def test_heads_backward_vs_fp32_oracle(ops):
+    B = 2
+    targets = make_targets(ops, B, first=7)
+    conf, loc = logits(B, 21)
+    run_heads(ops, B, conf, loc, targets)
+
+
+def test_heads_backward_with_activation_mask(ops):
+    B = 1
+    targets = make_targets(ops, B, first=3)
+    conf, loc = logits(B, 22, bg=2.0)
+    run_heads(ops, B, conf, loc, targets, use_bits=False, check_oracle=(0, 2, 5))
+
+
+def test_heads_backward_vs_dense_kernels_batch16(ops):
+    """The dense kernels on the scattered rows (ssd_conv2d_bwd_data / _bwd_weight) at a batch where the split logic of the
+    sparse weight gradient uses several splits."""
+    B = 16
+    targets = make_targets(ops, B, first=100)
+    conf, loc = logits(B, 23)
+    hgb, dxs, dws, dbs, xs, ws, (sl, sc) = run_heads(ops, B, conf, loc, targets, check_oracle=())
+    for l in (0, 1, 2):
+        n, h, s = NPC[l], HW[l], SIDE[l]
+        off = sum(HW[k] * NPC[k] for k in range(l))
+        packed = ops.head_grad_pack(sl.contiguous(), sc.contiguous(), h, n, 81, NPAD[l], off).view(B, s, s, NPAD[l])
+        wt = ops.weight_transpose(ws[l], NPAD[l])
+        ddx = ops.conv2d_bwd_data(packed, wt, xs[l], xs[l].shape, 1, 1, 1)
+        ddw, ddb = ops.conv2d_bwd_weight(xs[l], packed, n * 85, 3, 1, 1, 1)
+        a, b = dxs[l].float(), ddx.float()
+        assert (a - b).abs().max() <= 2.0 ** -7 * b.abs().max()        # each is one bf16 rounding away from the fp32 sum
+        assert (dws[l] - ddw).abs().max() <= 1e-3 * ddw.abs().max()
+        assert (dbs[l] - ddb).abs().max() <= 1e-3 * ddb.abs().max()
+
+
+def test_every_anchor_selected(ops):
+    """All-equal logits: every background CE ties at tau and `>=` (:372) selects every anchor -- 100 % density."""
+    B = 1
+    targets = make_targets(ops, B, first=5)
+    conf = torch.zeros((B, 8732, 81), dtype=torch.bfloat16, device="cuda")
+    loc = torch.zeros((B, 8732, 4), dtype=torch.bfloat16, device="cuda")
+    hgb, *_ = run_heads(ops, B, conf, loc, targets, check_oracle=(1, 3, 4, 5))
+    assert hgb.count.cpu().tolist()[:6] == list(HW)
+
+
+def test_bitwise_deterministic(ops):
+    B = 4
+    targets = make_targets(ops, B, first=60)
+    conf, loc = logits(B, 24)
+    r1 = run_heads(ops, B, conf, loc, targets, check_oracle=())
+    r2 = run_heads(ops, B, conf, loc, targets, check_oracle=())
+    for l in range(6):
+        assert torch.equal(r1[1][l].view(torch.int16), r2[1][l].view(torch.int16))
+        assert torch.equal(r1[2][l], r2[2][l]) and torch.equal(r1[3][l], r2[3][l])

@@ -26,7 +26,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_FWD_PER_IMAGE = 57.554e9
-FLOP_TRAIN_PER_IMAGE = 172.66e9 - 0.31e9   # fwd + dgrad + wgrad, first-layer dgrad not needed
+FLOP_TRAIN_PER_IMAGE = 172.66e9 - 0.31e9   # fwd + dgrad + wgrad, first-layer dgrad not needed (every head gradient row counted)
+FLOP_HEADS_FWD_PER_IMAGE = 2 * 4.231e9  # the twelve head convolutions
+# The heads' data + weight gradients are computed from the rows the loss selects (positives + mined negatives) only; the
+# rest of the dense 2 x FLOP_HEADS_FWD is multiplication by exact zeros and is NOT executed.  Rooflines below count the
+# FLOPs that run: the dense network minus that part, plus what the sparse kernels do for the measured batch's rows.
+FLOP_TRUNK_TRAIN_PER_IMAGE = FLOP_TRAIN_PER_IMAGE - 2 * FLOP_HEADS_FWD_PER_IMAGE
 PEAK_BF16_TFLOPS = 2500.0               # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 MATCH_BYTES_PER_ANCHOR = 53             # priors f64 in (32) + cls i32 + loc f32x4 + mask u8 out; + 20 B per gt box
@@ -233,8 +238,11 @@ def run_rank(args):
                    "per_gpu_batch": B, "global_batch": B * world,
                    "parallelism": "dp%d" % world if world > 1 else "single"},
         "loss_check": dict(loss_vals, status=status),
-        "frac_of_conv_gemm_roofline": round(FLOP_TRAIN_PER_IMAGE * value / (world * PEAK_BF16_TFLOPS * 1e12), 4),
     }
+    flops_step = executed_conv_flops(eng, B)          # of the last batch's gradient rows (sparse head backward) or dense
+    result["conv_flops_per_step"] = {"executed": flops_step, "dense_equivalent": FLOP_TRAIN_PER_IMAGE * B,
+                                     "note": "executed = dense network minus the head gradients' products with all-zero rows"}
+    result["frac_of_conv_gemm_roofline"] = round(flops_step / B * value / (world * PEAK_BF16_TFLOPS * 1e12), 4)
 
     if world > 1:
         result["comm"] = comm_report(torch, dist, model, backend, world, elapsed / args.steps, timed_steps,
@@ -251,6 +259,43 @@ def run_rank(args):
     if world > 1:
         dist.barrier()                          # rank 0 was still timing kernels: leave together
         dist.destroy_process_group()
+
+
+def executed_conv_flops(eng, B):
+    """Convolution FLOPs one step of batch B executes: the dense trunk + head forward, plus for the heads' backward either the
+    dense 2 x forward (dense path) or what the sparse kernels do for the rows of the engine's last loss call: per row of
+    level l the Z GEMM (npad x 9 Cin MACs) and the gathered weight gradient (the same count)."""
+    hgb = eng.head_grad_buffers(B)
+    if hgb is None:
+        return FLOP_TRAIN_PER_IMAGE * B
+    counts = hgb.count.cpu().tolist()
+    sparse = sum(2 * 2.0 * counts[l] * hgb.npad[l] * 9 * c for l, (_, _, c) in enumerate(eng.fm))
+    return FLOP_TRUNK_TRAIN_PER_IMAGE * B + sparse
+
+
+def calibration(torch, ops, target_ms=60.0):
+    """Same-run yardstick (dev entry ssd_dev_mfma_calibration): an LDS-fed bf16 MFMA loop on random operands without memory
+    traffic, >= 50 ms, with the in-kernel clock from s_memtime / s_memrealtime stamps (MI355X_MICROARCH.md, DVFS give-back 6)."""
+    import ctypes
+    from ssd_object_detection_amd import _lib
+    L = _lib.lib()
+    nwg = L.ssd_dev_mfma_calibration_workgroups()
+    stamps = torch.zeros((2 * nwg,), dtype=torch.int64, device="cuda")
+    sink = torch.empty((512 * nwg,), dtype=torch.float32, device="cuda")
+
+    def run(iters):
+        _lib.check(L.ssd_dev_mfma_calibration(iters, ops._ptr(stamps), ops._ptr(sink), ops._stream()))
+    it0 = 2000
+    t = timed(torch, lambda: run(it0), 3)                  # sizes the long run (and warms the clocks)
+    iters = max(it0, int(it0 * target_ms * 1e-3 / t))
+    t = timed(torch, lambda: run(iters), 1, warm=0)
+    st = stamps.view(nwg, 2).cpu().numpy().astype("float64")
+    import numpy as np
+    clk = float(np.median(st[:, 0] / np.maximum(st[:, 1], 1.0))) * 0.1      # x 100 MHz -> GHz
+    tf = L.ssd_dev_mfma_calibration_flops(iters) / t / 1e12
+    return {"kernel": "k_mfma_calibration: 256 workgroups x 8 waves, v_mfma_f32_16x16x32_bf16 fed by ds_read_b128 from LDS, random "
+                      "operands, no global traffic", "ms": round(t * 1e3, 2), "tflops": round(tf, 1),
+            "frac_of_nominal_peak": round(tf / PEAK_BF16_TFLOPS, 4), "in_kernel_clock_ghz": round(clk, 3)}
 
 
 def comm_report(torch, dist, model, backend, world, step_s, timed_steps, n_local, first):
@@ -305,20 +350,29 @@ def kernel_sections(np, torch, ops, model, eng, pset, batches, match_out, B, res
     else:
         _, dconf, dloc = ops.ssd_loss(pconf, ploc, cls, loc, mask)
         t_bwd = timed(torch, lambda: eng.backward(dloc, dconf), 3)
-    conv_flops = FLOP_TRAIN_PER_IMAGE * B
+    conv_flops = executed_conv_flops(eng, B)
     conv_time = t_fwd + t_bwd
+    cal = calibration(torch, ops)
+    result["calibration"] = cal
+    dom = dominant_kernel(torch, ops, eng, B)
     # memory-side traffic of the convolution launches of one step, from rocprofv3 PMC passes (separate --pmc FETCH_SIZE /
     # WRITE_SIZE runs, FETCH_SIZE doubled: gfx950 tallies 128-byte requests at 64 B, MI355X_MICROARCH.md "HBM"); the file
     # records the commit it was collected at.  Only valid for the batch it was collected at.
     conv_pmc, conv_pmc_file = pmc_profile("conv_pmc")
     conv_traffic = int(conv_pmc["conv_hbm_bytes_per_step"]) if (B == 64 and conv_pmc) else None
-    result["roofline"] = {
-        "bound": "mfma", "kernel": "all convolution launches of one step (k_conv3x3_patch32, k_conv3x3_wgrad_patch, k_conv_igemm_*, k_conv_wgrad_*, k_conv0_*)",
-        "achieved": round(conv_flops / conv_time / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(conv_flops / conv_time / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": conv_traffic,
-        "traffic_source": conv_pmc_file, "traffic_commit": (conv_pmc or {}).get("commit"),
-        "fwd_ms": round(t_fwd * 1e3, 3), "bwd_ms": round(t_bwd * 1e3, 3),
-        "fwd_tflops": round(FLOP_FWD_PER_IMAGE * B / t_fwd / 1e12, 2)}
+    agg = conv_flops / conv_time / 1e12
+    # `roofline` is the dominant kernel of the step (most device time in profiles/r03_bench_kernel_stats.csv), timed alone
+    # with HIP events on its launch stream; the aggregate over every convolution launch of a step is beside it.  Both against
+    # the nominal dense bf16 peak and against what this device sustained for the same instruction mix in this run.
+    result["roofline"] = dict(
+        dom, bound="mfma", peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(dom["achieved"] / PEAK_BF16_TFLOPS, 4),
+        frac_of_calibration=round(dom["achieved"] / cal["tflops"], 4), traffic=(conv_pmc or {}).get("dominant_kernel_hbm_bytes_per_launch"),
+        traffic_source=conv_pmc_file, traffic_commit=(conv_pmc or {}).get("commit"),
+        aggregate={"kernel": "all convolution launches of one step (forward + backward, two streams)",
+                   "achieved": round(agg, 2), "frac": round(agg / PEAK_BF16_TFLOPS, 4),
+                   "frac_of_calibration": round(agg / cal["tflops"], 4), "flops_executed": conv_flops,
+                   "traffic": conv_traffic, "fwd_ms": round(t_fwd * 1e3, 3), "bwd_ms": round(t_bwd * 1e3, 3),
+                   "fwd_tflops": round(FLOP_FWD_PER_IMAGE * B / t_fwd / 1e12, 2)})
 
     # ---- anchor matching (A3-A5): graph-replayed ----
     total_gt = gt[3]
@@ -374,8 +428,67 @@ def kernel_sections(np, torch, ops, model, eng, pset, batches, match_out, B, res
     pbytes = int(sum(sizes)) + B * 300 * 300 * 8 * 2
     result["roofline_prep"] = hbm_entry("ssd_image_resize_prep (k_image_resize_prep)", pbytes, t_prep, B)
 
+    # ---- BASELINE configs[1]: batch 32 bf16, anchor-match + loss only ----
+    result["config2_match_loss"] = config2_section(torch, ops, pset)
+
     # ---- BASELINE configs[4] anchor side: 24 564 anchors through priors -> match -> loss -> score/decode -> NMS ----
     result["cfg5_anchors"] = cfg5_section(torch, ops, B)
+
+
+def dominant_kernel(torch, ops, eng, B):
+    """k_conv3x3_wgrad_patch<16,2> (the weight gradients of the 3x3 / stride-1 layers on maps of 75 x 75 and larger): every
+    trunk layer whose weight-gradient dispatch resolves to it, launched alone on this stream with the step's own operands;
+    algorithmic FLOPs of those launches / their summed time."""
+    from ssd_object_detection_amd import _lib
+    L = _lib.lib()
+    c = eng._acts(B)
+    want = None
+    layers, flops, secs = [], 0.0, 0.0
+    for i, nd in enumerate(eng.nodes):
+        if nd["kind"] != "conv":
+            continue
+        plan = L.ssd_conv2d_bwd_weight_plan(B, nd["hin"], nd["hin"], nd["cin"], nd["cout"], nd["cout"], nd["k"], nd["stride"],
+                                            nd["pt"], nd["pl"], nd["hout"], nd["hout"])
+        name = L.ssd_conv_plan_name(plan).decode() if plan > 0 else ""
+        if "wgrad_patch<16,2>" not in name:
+            continue
+        want = name
+        wt, bt = eng.conv_params[i]
+        x, dy = c["acts"][i], c["gacts"][i + 1]
+        if x is None:
+            continue
+        t = timed(torch, lambda: ops.conv2d_bwd_weight(x, dy, nd["cout"], nd["k"], nd["stride"], nd["pt"], nd["pl"],
+                                                      dw=eng.view(wt, eng.grad), dbias=eng.view(bt, eng.grad), ws=eng._ws), 5)
+        layers.append("conv%d" % i)
+        secs += t
+        flops += 2.0 * B * nd["hout"] * nd["hout"] * nd["cout"] * 9 * nd["cin"]
+    return {"kernel": "%s (weight gradients of %s)" % (want, ", ".join(layers)),
+            "launches_per_step": len(layers), "us_per_step": round(secs * 1e6, 1), "achieved": round(flops / secs / 1e12, 2),
+            "flops": flops}
+
+
+def config2_section(torch, ops, pset):
+    """BASELINE configs[1]: SSD300, batch 32, bf16, anchor-match + loss only (the reference's default batch size,
+    config/default.yml:19) -- microseconds per image and HBM fractions of the two stages on their own."""
+    from ssd_object_detection_amd.data_loaders.synthetic import synth_batch_gt
+    B = 32
+    cls_l, box_l = synth_batch_gt(9000, B)
+    gt = ops.pack_gt(box_l, cls_l)
+    out = ops.match_encode(*gt, pset, 0.5)
+    t_match = graph_timed(torch, lambda: ops.match_encode(*gt, pset, 0.5, out=out), 50)
+    g = torch.Generator(device="cuda").manual_seed(32)
+    conf = torch.randn((B, pset.A, 81), generator=g, device="cuda").bfloat16()
+    loc = (0.5 * torch.randn((B, pset.A, 4), generator=g, device="cuda")).bfloat16()
+    t_loss = graph_timed(torch, lambda: ops.ssd_loss(conf, loc, *out), 30)
+    mbytes = B * pset.A * MATCH_BYTES_PER_ANCHOR + 20 * gt[3]
+    lbytes = B * pset.A * (2 * 81 * 2 + 2 * 4 * 2 + 21)
+    return {"workload": "BASELINE configs[1]: SSD300 batch 32 bf16, synthetic COCO 80-class boxes, anchor-match + loss only "
+                        "(loss with its dense gradient, ssd_loss_fwd_bwd)",
+            "match_encode_us_per_image": round(t_match / B * 1e6, 4), "match_GBs": round(mbytes / t_match / 1e9, 1),
+            "match_frac_of_hbm_peak": round(mbytes / t_match / 1e9 / PEAK_HBM_GBS, 4),
+            "loss_us_per_image": round(t_loss / B * 1e6, 4), "loss_GBs": round(lbytes / t_loss / 1e9, 1),
+            "loss_frac_of_hbm_peak": round(lbytes / t_loss / 1e9 / PEAK_HBM_GBS, 4),
+            "match_plus_loss_us_per_image": round((t_match + t_loss) / B * 1e6, 4)}
 
 
 def detect_section(torch, ops, pset, B, dtype, score_thresh=0.3, iou_thresh=0.45):

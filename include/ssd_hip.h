@@ -394,6 +394,18 @@ const char* ssd_conv_plan_name(int plan);
  * variant computes the same convolution).  SSD_ERR_VALUE for an unknown name. */
 int ssd_dev_knob(const char* name, int value);
 
+/* Measurement only (no reference counterpart, not on any product path): the inner loop of the convolution kernels without
+ * their memory traffic -- 256 workgroups x 8 waves, each wave `iters` x 32 bf16 16x16x32 MFMAs fed by ds_read_b128 fragment
+ * reads of random operands in LDS.  bench.py times it beside the train step: the rate this device sustains (devices of one
+ * model differ by ~12 % on such a loop) and the in-kernel clock.
+ *   stamps  DEVICE uint64[2 * ssd_dev_mfma_calibration_workgroups()]: per workgroup (delta s_memtime, delta s_memrealtime)
+ *           around the loop -> clock = delta s_memtime / delta s_memrealtime x 100 MHz
+ *   sink    DEVICE float[512 * workgroups], written and never read
+ *   flop count of one call: ssd_dev_mfma_calibration_flops(iters) */
+int ssd_dev_mfma_calibration_workgroups(void);
+double ssd_dev_mfma_calibration_flops(int iters);
+int ssd_dev_mfma_calibration(int iters, void* stamps, void* sink, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,6 +100,9 @@ _SIGNATURES = {
     "ssd_adam_step": (ctypes.c_int, [VP, VP, VP, VP, VP, ctypes.c_longlong, VP, VP] + [ctypes.c_float] * 5 + [VP]),
     "ssd_sgd_step": (ctypes.c_int, [VP, VP, VP, ctypes.c_longlong, VP, VP, ctypes.c_float, ctypes.c_float, VP]),
     "ssd_dev_knob": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
+    "ssd_dev_mfma_calibration_workgroups": (ctypes.c_int, []),
+    "ssd_dev_mfma_calibration_flops": (ctypes.c_double, [ctypes.c_int]),
+    "ssd_dev_mfma_calibration": (ctypes.c_int, [ctypes.c_int, VP, VP, VP]),
     "ssd_conv2d_fwd_plan": (ctypes.c_int, [ctypes.c_int] * 12 + [ctypes.c_size_t]),
     "ssd_conv2d_head_fwd_plan": (ctypes.c_int, [ctypes.c_int] * 6 + [ctypes.c_size_t]),
     "ssd_conv2d_bwd_data_plan": (ctypes.c_int, [ctypes.c_int] * 12 + [ctypes.c_size_t]),

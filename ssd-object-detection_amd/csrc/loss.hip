@@ -37,7 +37,7 @@ struct LossWs {                              // layout of the caller's workspace
     float* ce_bg;                            // [n] masked background CE (0 at positives)
     float* lse;                              // [n] logsumexp per anchor
     int* hist1;                              // [NREP][H1STRIDE] | hist2 [HB2] | hist3 [HB3] | counters[8]  (zeroed per call)
-    int* hist1s;                             // [H1STRIDE] replicas collapsed (k_loss_collapse)
+    int* hist1s;                             // [H1STRIDE] replicas collapsed (by k_loss_hist<2>)
     int* hist2;
     int* hist3;
     int* counters;                           // [4..7] = select result {tau_bits, n_neg lo, n_neg hi, ok}; [3] = P
@@ -233,29 +233,35 @@ __device__ __forceinline__ int find_bin(const int* __restrict__ hist, int nb, lo
     return s_bin;
 }
 
-// Sum the NREP replicas of the level-1 histogram (and of P) into hist1s; one thread per bin.
-__global__ __launch_bounds__(WG) void k_loss_collapse(LossWs w) {
-    const int b = blockIdx.x * WG + threadIdx.x;
-    if (b > HB1) return;
-    int v[NREP];
-#pragma unroll
-    for (int rp = 0; rp < NREP; ++rp) v[rp] = w.hist1[(size_t)rp * H1STRIDE + b];
-    int sum = 0;
-#pragma unroll
-    for (int rp = 0; rp < NREP; ++rp) sum += v[rp];
-    w.hist1s[b] = sum;
-}
-
 __device__ __forceinline__ int load_num_pos(const LossWs& w) { return w.hist1s[HB1]; }
 
 // Radix select, levels 2 and 3: histogram the next digit of the keys that share the prefix so far.
+// LEVEL 2 also collapses the NREP replicas of the level-1 histogram (and of P): every workgroup sums them into its own
+// LDS copy (132 KB from L2 each: cheaper than the launch a separate collapse kernel costs), workgroup 0 stores the sums for
+// the kernels behind (hist1s).
 template <int LEVEL>
 __global__ __launch_bounds__(WG) void k_loss_hist(size_t n, LossWs w) {
     __shared__ int s_scan[WG];
     __shared__ int s_hist[HB2];
-    const long long k = 3ll * load_num_pos(w);
+    __shared__ int s_h1[LEVEL == 2 ? H1STRIDE : 1];
+    const int* h1 = w.hist1s;
+    if constexpr (LEVEL == 2) {
+        for (int b = threadIdx.x; b <= HB1; b += WG) {
+            int v[NREP];
+#pragma unroll
+            for (int rp = 0; rp < NREP; ++rp) v[rp] = w.hist1[(size_t)rp * H1STRIDE + b];
+            int sum = 0;
+#pragma unroll
+            for (int rp = 0; rp < NREP; ++rp) sum += v[rp];
+            s_h1[b] = sum;
+            if (blockIdx.x == 0) w.hist1s[b] = sum;
+        }
+        __syncthreads();
+        h1 = s_h1;
+    }
+    const long long k = 3ll * h1[HB1];
     long long kin, above;
-    const int b1 = find_bin(w.hist1s, HB1, k, &kin, &above, s_scan);
+    const int b1 = find_bin(h1, HB1, k, &kin, &above, s_scan);
     unsigned prefix = (unsigned)b1, shift = 21;
     int nb = HB2;
     if (LEVEL == 3) {
@@ -458,10 +464,20 @@ __device__ __forceinline__ int block_sum_int(int v, int* s4) {
     return s4[0] + s4[1] + s4[2] + s4[3];
 }
 
+// (also the last step of the radix select: every workgroup evaluates it from the three histograms -- the separate
+// one-workgroup launch cost more than 384 redundant evaluations -- and workgroup (0, 0) stores it for the kernels behind)
 __global__ __launch_bounds__(WG) void k_hg_count(const uint8_t* __restrict__ mask, LossWs w, HeadGradsDev h) {
     __shared__ int s4[4];
+    __shared__ int s_scan[WG];
     const int b = blockIdx.x, l = blockIdx.y;
-    const Select sel = load_select(w);
+    const Select sel = finish_select(w, s_scan);
+    if (b == 0 && l == 0 && threadIdx.x == 0) {
+        w.counters[4] = (int)sel.tau_bits;
+        w.counters[5] = (int)(sel.n_neg & 0xffffffffll);
+        w.counters[6] = (int)(sel.n_neg >> 32);
+        w.counters[7] = sel.ok;
+        w.counters[3] = load_num_pos(w);
+    }
     const float tau = __uint_as_float(sel.tau_bits);
     int c = 0;
     for (int pix = threadIdx.x; pix < h.hw[l]; pix += WG) c += hg_pixel_flag(h, mask, w, l, b, pix, sel, tau) ? 1 : 0;
@@ -565,18 +581,17 @@ __global__ __launch_bounds__(WG) void k_loss_grad_rows(const __hip_bfloat16* __r
 // the launches both forms share: conf read once, exact radix select of tau
 template <typename T>
 void launch_loss_select(const void* conf, const void* loc, const int32_t* cls, const float* gloc, const uint8_t* mask,
-                        size_t n, int C, LossWs w, hipStream_t s, size_t lds) {
+                        size_t n, int C, LossWs w, hipStream_t s, size_t lds, bool select_launch = true) {
     const size_t nblk = (n + ROWS - 1) / ROWS;
     const unsigned pgrid = (unsigned)min((size_t)MAX_PERSIST, nblk);
     if (C == 81)
         hipLaunchKernelGGL((k_loss_rows<T, 81>), dim3(pgrid), dim3(WG), lds, s, (const T*)conf, (const T*)loc, cls, gloc, mask, n, C, w);
     else
         hipLaunchKernelGGL((k_loss_rows<T, 0>), dim3(pgrid), dim3(WG), lds, s, (const T*)conf, (const T*)loc, cls, gloc, mask, n, C, w);
-    hipLaunchKernelGGL(k_loss_collapse, dim3((HB1 + WG) / WG), dim3(WG), 0, s, w);
     const unsigned hgrid = (unsigned)min((size_t)256, (n + WG - 1) / WG);
     hipLaunchKernelGGL(k_loss_hist<2>, dim3(hgrid), dim3(WG), 0, s, n, w);
     hipLaunchKernelGGL(k_loss_hist<3>, dim3(hgrid), dim3(WG), 0, s, n, w);
-    hipLaunchKernelGGL(k_loss_select, dim3(1), dim3(WG), 0, s, w);
+    if (select_launch) hipLaunchKernelGGL(k_loss_select, dim3(1), dim3(WG), 0, s, w);
 }
 
 template <typename T>
@@ -639,7 +654,7 @@ int ssd_loss_fwd_bwd_heads(const void* conf, const void* loc, int dtype, const i
     const size_t nblk = (n + ROWS - 1) / ROWS;
     const size_t lds = ((size_t)ROWS * C * sizeof(float) + 15) / 16 * 16;
     if (hipMemsetAsync(w.hist1, 0, w.zero_bytes, s) != hipSuccess) return SSD_ERR_LAUNCH;
-    launch_loss_select<T>(conf, loc, gt_cls, gt_loc, gt_mask, n, C, w, s, lds);
+    launch_loss_select<T>(conf, loc, gt_cls, gt_loc, gt_mask, n, C, w, s, lds, false);
     hipLaunchKernelGGL(k_hg_count, dim3(B, hg->levels), dim3(WG), 0, s, gt_mask, w, h);
     hipLaunchKernelGGL(k_hg_assign, dim3(B, hg->levels), dim3(WG), 0, s, gt_mask, w, h);
     hipLaunchKernelGGL(k_loss_grad_rows, dim3((unsigned)nblk), dim3(WG), 0, s, (const T*)conf, (const T*)loc, gt_cls, gt_loc,

@@ -170,16 +170,27 @@ __global__ __launch_bounds__(256) void k_hz_col2im(CArgs a) {
     const int y = rem / lv.W, x = rem - y * lv.W;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int N = 9 * lv.Cin;
+    // the nine row indices first (independent loads, all in flight together), then the rows that exist, in tap order
+    int r[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int qy = y - (t / 3 - 1), qx = x - (t % 3 - 1);
-        if ((unsigned)qy >= (unsigned)lv.H || (unsigned)qx >= (unsigned)lv.W) continue;
-        const int r = lv.rop[b * hw + qy * lv.W + qx];
-        if (r < 0) continue;
-        const float4* zp = reinterpret_cast<const float4*>(lv.z + (long long)r * N + t * lv.Cin + cg * 8);
-        const float4 v0 = zp[0], v1 = zp[1];
-        acc[0] += v0.x; acc[1] += v0.y; acc[2] += v0.z; acc[3] += v0.w;
-        acc[4] += v1.x; acc[5] += v1.y; acc[6] += v1.z; acc[7] += v1.w;
+        const bool in = (unsigned)qy < (unsigned)lv.H && (unsigned)qx < (unsigned)lv.W;
+        r[t] = in ? lv.rop[b * hw + qy * lv.W + qx] : -1;
+    }
+    float4 v0[9], v1[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        v0[t] = v1[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r[t] >= 0) {
+            const float4* zp = reinterpret_cast<const float4*>(lv.z + (long long)r[t] * N + t * lv.Cin + cg * 8);
+            v0[t] = zp[0]; v1[t] = zp[1];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {                             // (adding the +0 of an absent row changes no bit)
+        acc[0] += v0[t].x; acc[1] += v0[t].y; acc[2] += v0[t].z; acc[3] += v0[t].w;
+        acc[4] += v1[t].x; acc[5] += v1[t].y; acc[6] += v1[t].z; acc[7] += v1[t].w;
     }
     uint4 v = make_uint4((unsigned)f2bf(acc[0]) | ((unsigned)f2bf(acc[1]) << 16), (unsigned)f2bf(acc[2]) | ((unsigned)f2bf(acc[3]) << 16),
                          (unsigned)f2bf(acc[4]) | ((unsigned)f2bf(acc[5]) << 16), (unsigned)f2bf(acc[6]) | ((unsigned)f2bf(acc[7]) << 16));
@@ -218,6 +229,18 @@ struct WArgs {
 };
 
 constexpr int WT_TILE = 64 * 512;                          // one [64 rows][256 ch] image
+// The host fixes the MAXIMUM number of pixel splits of a level (it does not know the row count); the kernels use only as
+// many as give every active split at least HW_MIN_ROWS rows, so a level with few rows neither writes nor re-reads slabs
+// of splits that would be empty.  Rows per active split (a multiple of 64) and their number, from the device-side count:
+constexpr int HW_MIN_ROWS = 768;
+__device__ __forceinline__ int hw_rows_per_split(int cnt, int nsplit_max) {
+    const int per = max((cnt + nsplit_max - 1) / nsplit_max, HW_MIN_ROWS);
+    return (per + 63) / 64 * 64;
+}
+__device__ __forceinline__ int hw_active_splits(int cnt, int nsplit_max) {
+    const int per = hw_rows_per_split(cnt, nsplit_max);
+    return max(1, (cnt + per - 1) / per);
+}
 __global__ __launch_bounds__(512) void k_hw_gather(WArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -234,7 +257,8 @@ __global__ __launch_bounds__(512) void k_hw_gather(WArgs a) {
     const int bx = tile % ctiles, by = tile / ctiles;
     const int col0 = bx * 256, co0 = by * 256;
     const int cnt = a.count[l];
-    const int m_per_split = (((cnt + lv.nsplit - 1) / lv.nsplit) + 63) / 64 * 64;
+    if (split >= hw_active_splits(cnt, lv.nsplit)) return;     // (split 0 always runs: zero rows -> zero slab)
+    const int m_per_split = hw_rows_per_split(cnt, lv.nsplit);
     const int m_begin = min(cnt, split * m_per_split);
     const int m_end = min(cnt, m_begin + m_per_split);
     const int hw = lv.H * lv.W;
@@ -407,6 +431,7 @@ struct RLevel {
 struct RArgs {
     int levels;
     RLevel lv[SSD_MAX_LEVELS];
+    const int* count;
 };
 
 __global__ __launch_bounds__(256) void k_hw_reduce(RArgs a) {
@@ -415,11 +440,12 @@ __global__ __launch_bounds__(256) void k_hw_reduce(RArgs a) {
     for (int k = 1; k < SSD_MAX_LEVELS; ++k) l += (k < a.levels && (int)blockIdx.x >= a.lv[k].blk0) ? 1 : 0;
     const RLevel lv = a.lv[l];
     const int blk = blockIdx.x - lv.blk0;
+    const int nsplit = hw_active_splits(a.count[l], lv.nsplit);
     if (blk < lv.nbw) {
         const long long i = ((long long)blk * 256 + threadIdx.x) * 4;
         if (i >= lv.nw) return;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int z = 0; z < lv.nsplit; ++z) {
+        for (int z = 0; z < nsplit; ++z) {
             const float4 v = *reinterpret_cast<const float4*>(lv.slab_w + (long long)z * lv.sw + i);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
@@ -428,7 +454,7 @@ __global__ __launch_bounds__(256) void k_hw_reduce(RArgs a) {
         const int i = (blk - lv.nbw) * 256 + threadIdx.x;
         if (i >= lv.nb || !lv.db) return;
         float s = 0.f;
-        for (int z = 0; z < lv.nsplit; ++z) s += lv.slab_b[(long long)z * lv.sb + i];
+        for (int z = 0; z < nsplit; ++z) s += lv.slab_b[(long long)z * lv.sb + i];
         lv.db[i] = s;
     }
 }
@@ -526,7 +552,7 @@ int ssd_heads_bwd_weight_sparse(const ssd_head_grads* hg, const ssd_head_layers*
     RArgs ra;
     wa.levels = ra.levels = hg->levels;
     wa.B = B;
-    wa.count = hg->count;
+    wa.count = ra.count = hg->count;
     char* p = static_cast<char*>(ws);
     int blk = 0, rblk = 0;
     for (int l = 0; l < SSD_MAX_LEVELS; ++l) {

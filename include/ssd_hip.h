@@ -20,6 +20,8 @@
  *     wrapper maps SSD_ERR_ASSERT to AssertionError and SSD_ERR_VALUE to ValueError, the
  *     exception types the reference raises at the same seams.
  *   - Layouts: boxes are (cx, cy, w, h); activations NHWC; conv weights [Cout][kh][kw][Cin].
+ *   - Alignment: every tensor pointer and every workspace 16-byte aligned (hipMalloc gives 256); the loc / conf outputs of
+ *     ssd_conv2d_head_fwd 4-byte aligned.  Kernels use 16-byte vector accesses on them without checking.
  */
 #ifndef SSD_HIP_H
 #define SSD_HIP_H
@@ -229,20 +231,7 @@ int ssd_conv2d_head_fwd(const void* x, const void* w, const float* bias, void* l
 int ssd_conv2d_bwd_data(const void* dy, const void* w_t, const void* relu_src, void* dx, int B, int H, int W, int Cin,
                         int Cout_pad, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int accumulate,
                         void* ws, size_t ws_bytes, void* stream);
-/* Winograd F(2x2,3x3) form of the 3x3 / stride 1 / pad 1 layers (same Conv2D of models/ssd_model.py:74-171 and its
- * data gradient, 2.25x fewer MACs, fp16 transformed operands with fp32 accumulation; csrc/wino.hip).
- * ssd_wino_weights: u = G g G^T of w[Cout][3][3][Cin] bf16 (x 2^w_shift), ssd_wino_weights_bytes(Cout, Cin) bytes, once
- * per weight update; for the data gradient pass ssd_weight_transpose's output with Cout / Cin swapped.
- * Operands enter fp16 as value * 2^in_shift (exact; keeps small gradients out of fp16's subnormals), the result is
- * scaled back by 2^-(in_shift + w_shift).  Shapes: Cin % 64 == 0, Cout % 64 == 0, H, W >= 16 (ssd_conv3x3_wino_supported);
- * anything else returns SSD_ERR_VALUE before a launch.  y == NULL with y_pool != NULL: only the pooled map leaves. */
-size_t ssd_wino_weights_bytes(int Cout, int Cin);
-int ssd_wino_weights(const void* w, void* u, int Cout, int Cin, int w_shift, void* stream);
-int ssd_conv3x3_wino_supported(int B, int H, int W, int Cin, int Cout);
-int ssd_conv3x3_wino_fwd(const void* x, const void* u, const float* bias, void* y, void* y_pool, void* pool_code, int B, int H,
-                         int W, int Cin, int Cout, int relu, int Hp, int Wp, int in_shift, int w_shift, void* stream);
-int ssd_conv3x3_wino_bwd_data(const void* dy, const void* u_t, const void* relu_src, void* dx, int B, int H, int W, int Cin,
-                              int Cout, int accumulate, int in_shift, int w_shift, void* stream);
+
 /* ReLU sign bits.  ssd_conv2d_fwd_relubits = ssd_conv2d_fwd (relu = 1) that also writes one byte per pixel and 8 output
  * channels (bit k: channel 8c + k > 0), relu_bits [B*Ho*Wo][Cout/8]; ssd_conv2d_bwd_data_bits = ssd_conv2d_bwd_data with
  * its ReLU mask read from such bytes instead of the bf16 activation (relu_src): identical results, 16x fewer mask bytes --
@@ -366,11 +355,11 @@ int ssd_sgd_step(float* param, const float* grad, void* param_bf16, long long n,
  * ---------------------------------------------------------------------------------------- */
 enum ssd_conv_plan {
     SSD_PLAN_KERNEL_MASK = 0xff,
-    SSD_PLAN_C64B = 1, SSD_PLAN_C64, SSD_PLAN_P32_64, SSD_PLAN_P32_128, SSD_PLAN_PATCH_64, SSD_PLAN_PATCH_128, SSD_PLAN_8PH,
+    SSD_PLAN_C64B = 1, SSD_PLAN_P32_64, SSD_PLAN_P32_128, SSD_PLAN_8PH,
     SSD_PLAN_DMA_256_256, SSD_PLAN_DMA_256_128, SSD_PLAN_DMA_256_64, SSD_PLAN_DMA_128_64, SSD_PLAN_DMA_128_128,
-    SSD_PLAN_REG_64, SSD_PLAN_REG_128, SSD_PLAN_CONV0_FWD, SSD_PLAN_P512,
+    SSD_PLAN_CONV0_FWD, SSD_PLAN_P512,
     SSD_PLAN_WG_FIRST = 32, SSD_PLAN_WG_PATCH_16x16, SSD_PLAN_WG_PATCH_6x40, SSD_PLAN_WG_PATCH_10x24, SSD_PLAN_WG_TILE,
-    SSD_PLAN_WG_GENERIC, SSD_PLAN_WG_DMA,
+    SSD_PLAN_WG_GENERIC,
     SSD_PLAN_F_FLAT = 0x100,         /* strip blocks over a narrow map */
     SSD_PLAN_F_ROWFLAT = 0x200,      /* one strip of rows over all images */
     SSD_PLAN_F_SPLITK = 0x400,       /* split-K partial sums + k_igemm_finalize */

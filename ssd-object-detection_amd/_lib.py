@@ -78,11 +78,6 @@ _SIGNATURES = {
     "ssd_conv2d_bwd_weight_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 7),
     "ssd_conv2d_bwd_weight": (ctypes.c_int, [VP, VP, VP, VP] + [ctypes.c_int] * 12 + [VP, ctypes.c_size_t, VP]),
     "ssd_weight_transpose": (ctypes.c_int, [VP, VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, VP]),
-    "ssd_wino_weights_bytes": (ctypes.c_size_t, [ctypes.c_int] * 2),
-    "ssd_wino_weights": (ctypes.c_int, [VP, VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, VP]),
-    "ssd_conv3x3_wino_supported": (ctypes.c_int, [ctypes.c_int] * 5),
-    "ssd_conv3x3_wino_fwd": (ctypes.c_int, [VP] * 6 + [ctypes.c_int] * 10 + [VP]),
-    "ssd_conv3x3_wino_bwd_data": (ctypes.c_int, [VP] * 4 + [ctypes.c_int] * 8 + [VP]),
     "ssd_cast_bf16": (ctypes.c_int, [VP, VP, ctypes.c_longlong, VP]),
     "ssd_image_prep": (ctypes.c_int, [VP, VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, VP]),
     "ssd_image_resize_prep": (ctypes.c_int, [VP, VP, VP, VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, VP]),

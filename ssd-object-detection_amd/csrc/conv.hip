@@ -68,131 +68,6 @@ __global__ void k_igemm_finalize(ConvGeom g, Epilogue ep) {
     epi_store<EPI>(v, m, n, full, g, ep);
 }
 
-template <int BN, int EPI, int CT, int PT>
-__device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[CT][PT], const ConvGeom& g, const Epilogue& ep, int m0,
-                                              int n0, int wave_m, int wave_n, int lane) {
-    int mrow[PT];
-#pragma unroll
-    for (int p = 0; p < PT; ++p) {
-        const int m = m0 + wave_m * 64 + p * 16 + (lane & 15);
-        mrow[p] = m < g.M ? m : -1;
-    }
-    conv_epilogue_rows<EPI, CT, PT>(acc, g, ep, mrow, n0 + wave_n * (16 * CT), lane);
-}
-
-template <int BN, int EPI>
-__global__ __launch_bounds__(WG) void k_conv_igemm(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ w,
-                                                   ConvGeom g, Epilogue ep) {
-    constexpr int BM = 128;
-    constexpr int CT = BN / 32;              // 16-wide channel tiles per wave
-    constexpr int PT = 4;                    // 16-wide pixel tiles per wave
-    constexpr int WROWS = BN / 32;           // weight rows staged per thread
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    auto s_x = [&](int buf) { return smem + buf * ((BM + BN) * 128); };
-    auto s_w = [&](int buf) { return smem + buf * ((BM + BN) * 128) + BM * 128; };
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wave_m = wave & 1, wave_n = wave >> 1;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int slot = tid & 7, r0 = tid >> 3;
-
-    // per-thread staging rows
-    int ybase[4], xbase[4];
-    long long ibase[4];
-    bool mvalid[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + r0 + 32 * j;
-        mvalid[j] = m < g.M;
-        const int mm = mvalid[j] ? m : 0;
-        const int b = fdiv(mm, g.d_hw);
-        const int rem = mm - b * g.d_hw.d;
-        const int oy = fdiv(rem, g.d_w);
-        const int ox = rem - oy * g.d_w.d;
-        ybase[j] = oy * g.mul - g.pad_t;
-        xbase[j] = ox * g.mul - g.pad_l;
-        ibase[j] = (long long)b * g.H * g.W;
-    }
-    // k state of this thread's chunk slot
-    int tap = slot / g.cpt, cc = slot - tap * g.cpt;
-    int kh = tap / g.KW, kw = tap - kh * g.KW;
-    int q = slot;
-
-    uint4 rx[4], rw[WROWS];
-    auto load_tiles = [&]() {
-        const bool kvalid = q < g.nchunks;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int ny = ybase[j] + kh, nx = xbase[j] + kw;
-            bool ok = kvalid && mvalid[j];
-            int iy = ny, ix = nx;
-            if (g.div > 1) {
-                ok = ok && ny >= 0 && nx >= 0 && (ny % g.div == 0) && (nx % g.div == 0);
-                iy = ny / g.div;
-                ix = nx / g.div;
-            }
-            ok = ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
-            rx[j] = make_uint4(0, 0, 0, 0);
-            if (ok) rx[j] = *reinterpret_cast<const uint4*>(x + ((ibase[j] + (long long)iy * g.W + ix) * g.C + cc * 8));
-        }
-#pragma unroll
-        for (int j = 0; j < WROWS; ++j) {
-            const int n = n0 + r0 + 32 * j;
-            rw[j] = make_uint4(0, 0, 0, 0);
-            if (kvalid && n < g.N) rw[j] = *reinterpret_cast<const uint4*>(w + ((long long)n * g.ldw + (long long)q * 8));
-        }
-        // advance to the next k-step (8 chunks ahead)
-        q += 8;
-        cc += 8;
-        while (cc >= g.cpt) {
-            cc -= g.cpt;
-            if (++kw == g.KW) { kw = 0; ++kh; }
-        }
-    };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<uint4*>(s_x(buf) + swz(r0 + 32 * j, slot)) = rx[j];
-#pragma unroll
-        for (int j = 0; j < WROWS; ++j) *reinterpret_cast<uint4*>(s_w(buf) + swz(r0 + 32 * j, slot)) = rw[j];
-    };
-
-    f32x4_t acc[CT][PT];
-#pragma unroll
-    for (int c = 0; c < CT; ++c)
-#pragma unroll
-        for (int p = 0; p < PT; ++p) acc[c][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    const int nks = (g.nchunks + 7) >> 3;
-    load_tiles();
-    store_tiles(0);
-    __syncthreads();
-    const int frow = lane & 15, fk = lane >> 4;
-    for (int ks = 0; ks < nks; ++ks) {
-        const int cur = ks & 1;
-        const bool more = ks + 1 < nks;
-        if (more) load_tiles();
-#pragma unroll
-        for (int ksub = 0; ksub < 2; ++ksub) {
-            bf16x8_t fx[PT], fw[CT];
-#pragma unroll
-            for (int p = 0; p < PT; ++p)
-                fx[p] = *reinterpret_cast<const bf16x8_t*>(s_x(cur) + swz(wave_m * 64 + p * 16 + frow, ksub * 4 + fk));
-#pragma unroll
-            for (int c = 0; c < CT; ++c)
-                fw[c] = *reinterpret_cast<const bf16x8_t*>(s_w(cur) + swz(wave_n * (BN / 2) + c * 16 + frow, ksub * 4 + fk));
-#pragma unroll
-            for (int c = 0; c < CT; ++c)
-#pragma unroll
-                for (int p = 0; p < PT; ++p)
-                    acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[c], fx[p], acc[c][p], 0, 0, 0);
-        }
-        if (more) store_tiles(cur ^ 1);
-        __syncthreads();
-    }
-
-    conv_epilogue<BN, EPI, CT, PT>(acc, g, ep, m0, n0, wave_m, wave_n, lane);
-}
-
 // ------------------------------------------------------------------------------------------------
 // Implicit GEMM, LDS-DMA version: tiles go global -> LDS directly (global_load_lds_dwordx4: per-lane
 // gather address, wave-uniform 1 KiB LDS destination, no VGPR staging, no ds_write).  The swizzled LDS
@@ -636,138 +511,14 @@ __global__ __launch_bounds__(512) void k_conv_igemm_8ph(const bf16_raw* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// 3x3 / stride 1 / pad 1 convolution with an LDS-resident input patch (forward, and data gradient with the
-// transposed weights).  A workgroup owns a 16x16 block of output pixels of one image and BN output channels.
-// Per 64-channel chunk of the input, the 18x18-pixel halo patch is brought into LDS ONCE (LDS-DMA) and all nine
-// taps read their MFMA fragments from it at shifted addresses; only the [BN][64] weight slice of each tap is
-// streamed (double-buffered).  Compared with the generic implicit GEMM this removes the 9x re-staging of the
-// activations: ~100 MACs per byte brought into the CU even at N = 64, where the generic 256x64 tile has 26 and
-// is bound by the CU's ~28 B/clk L2 ingest.
+// Halo patch of a 16x16 block of output pixels (3x3 / stride 1 / pad 1 kernels below)
 constexpr int PATCH_W = 18;
 constexpr int PATCH_PIX = PATCH_W * PATCH_W;               // 324
-constexpr int PATCH_INSTR = (PATCH_PIX * 8 + 63) / 64;     // 41 one-KiB DMA instructions
-constexpr int PATCH_BYTES = PATCH_INSTR * 1024;            // 41984
-
-template <int BN, int EPI>
-__global__ __launch_bounds__(512) void k_conv3x3_patch(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ w,
-                                                       ConvGeom g, Epilogue ep, int tiles_x, int tiles_y) {
-    constexpr int CT = BN / 32;
-    constexpr int PT = 4;
-    constexpr int WI = BN / 64;                              // weight DMA instructions per wave per tap
-    constexpr int PI = (PATCH_INSTR + 7) / 8;                // patch DMA instructions per wave per chunk (<= 6)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // LDS: two weight buffers + ONE patch buffer = 58 / 75 KB, so that two workgroups share a CU and cover each other's
-    // barrier and DMA waits (a second patch buffer or a third weight buffer would drop that to one and was slower)
-    auto s_w = [&](int buf) { return smem + buf * (BN * 128); };
-    auto s_p = [&](int) { return smem + 2 * (BN * 128); };
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_m = wave & 3, wave_n = wave >> 2;
-    int t = blockIdx.x;
-    const int tx = t % tiles_x; t /= tiles_x;
-    const int ty = t % tiles_y;
-    const int b = t / tiles_y;
-    const int y0 = ty * 16, x0 = tx * 16, n0 = blockIdx.y * BN;
-
-    // patch DMA ownership: instruction i = wave + 8j; lane L fills 16-byte slot S = 64 i + L of the swizzled image
-    long long poff[PI];
-#pragma unroll
-    for (int j = 0; j < PI; ++j) {
-        const int i = wave + 8 * j;
-        const int S = i * 64 + lane;
-        const int pr = S >> 4, pos = S & 15;
-        const int pp = 2 * pr + (pos >> 3);
-        const int c = (pos & 7) ^ (pr & 7);
-        const int py = pp / PATCH_W, px = pp - py * PATCH_W;
-        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-        const bool ok = i < PATCH_INSTR && pp < PATCH_PIX && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
-        poff[j] = ok ? (((long long)b * g.H + iy) * g.W + ix) * g.C + c * 8 : -1;
-    }
-    // weight DMA ownership (same scheme as k_conv_igemm_dma, 8 waves)
-    const int rl = 2 * (lane >> 4) + ((lane >> 3) & 1);
-    const int wslot = (lane & 7) ^ (4 * (wave & 1) + (lane >> 4));
-    long long woff[WI];
-#pragma unroll
-    for (int j = 0; j < WI; ++j) {
-        const int i = (wave & 1) + 2 * ((wave >> 1) + 4 * j);
-        const int n = n0 + 8 * i + rl;
-        woff[j] = n < g.N ? (long long)n * g.ldw + wslot * 8 : -1;
-    }
-    const int nchunk = g.C >> 6;
-    const int nsteps = nchunk * 9;
-
-    auto dma_patch = [&](int chunk, int buf) {
-#pragma unroll
-        for (int j = 0; j < PI; ++j) {
-            const int i = wave + 8 * j;
-            if (i < PATCH_INSTR) {
-                const bf16_raw* src = poff[j] >= 0 ? x + poff[j] + chunk * 64 : reinterpret_cast<const bf16_raw*>(g_zero16);
-                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(s_p(buf) + i * 1024), 16, 0, 0);
-            }
-        }
-    };
-    auto dma_w = [&](int step, int buf) {
-        const int chunk = step / 9, tap = step - chunk * 9;
-#pragma unroll
-        for (int j = 0; j < WI; ++j) {
-            const int i = (wave & 1) + 2 * ((wave >> 1) + 4 * j);
-            const bf16_raw* src = woff[j] >= 0 ? w + woff[j] + tap * g.C + chunk * 64 : reinterpret_cast<const bf16_raw*>(g_zero16);
-            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(s_w(buf) + i * 1024), 16, 0, 0);
-        }
-    };
-
-    f32x4_t acc[CT][PT];
-#pragma unroll
-    for (int c = 0; c < CT; ++c)
-#pragma unroll
-        for (int p = 0; p < PT; ++p) acc[c][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    dma_patch(0, 0);
-    dma_w(0, 0);
-    const int frow = lane & 15, fk = lane >> 4;
-    int chunk = 0, tap = 0, kh = 0, kw = 0;
-    for (int s = 0; s < nsteps; ++s) {
-        if (tap == 0 && s > 0) {
-            __syncthreads();                              // every wave is done with the previous chunk's patch
-            dma_patch(chunk, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (s + 1 < nsteps) dma_w(s + 1, (s + 1) & 1);
-        const char* pb = s_p(chunk & 1);
-        const char* wb = s_w(s & 1);
-#pragma unroll
-        for (int ksub = 0; ksub < 2; ++ksub) {
-            bf16x8_t fx[PT], fw[CT];
-#pragma unroll
-            for (int p = 0; p < PT; ++p) {
-                const int pix = (4 * wave_m + p + kh) * PATCH_W + kw + frow;
-                fx[p] = *reinterpret_cast<const bf16x8_t*>(pb + swz(pix, ksub * 4 + fk));
-            }
-#pragma unroll
-            for (int c = 0; c < CT; ++c)
-                fw[c] = *reinterpret_cast<const bf16x8_t*>(wb + swz(wave_n * (16 * CT) + c * 16 + frow, ksub * 4 + fk));
-#pragma unroll
-            for (int c = 0; c < CT; ++c)
-#pragma unroll
-                for (int p = 0; p < PT; ++p)
-                    acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[c], fx[p], acc[c][p], 0, 0, 0);
-        }
-        if (++kw == 3) { kw = 0; ++kh; }
-        if (++tap == 9) { tap = 0; kh = 0; kw = 0; ++chunk; }
-    }
-    int mrow[PT];
-#pragma unroll
-    for (int p = 0; p < PT; ++p) {
-        const int y = y0 + 4 * wave_m + p, xx = x0 + (lane & 15);
-        mrow[p] = (y < g.Ho && xx < g.Wo) ? (b * g.Ho + y) * g.Wo + xx : -1;
-    }
-    conv_epilogue_rows<EPI, CT, PT>(acc, g, ep, mrow, n0 + wave_n * (16 * CT), lane);
-}
 
 // ------------------------------------------------------------------------------------------------
-// Second form of the LDS-patch kernel (default): 32-channel chunks, linear padded images, two workgroups per CU.
+// 3x3 / stride 1 / pad 1 convolution with an LDS-resident input patch (forward, and data gradient with the transposed
+// weights): the halo patch of a block is brought into LDS once per channel chunk and all nine taps read their MFMA
+// fragments from it at shifted addresses; only the weight slice of a tap streams.  32-channel chunks, linear padded images, two workgroups per CU.
 //   * patch image: one 96-byte row per halo pixel (64 B of channels + 32 B pad).  The pitch makes every shifted
 //     ds_read_b128 conflict-free WITHOUT an address swizzle, so a fragment address is a per-lane base + immediate
 //     (the swizzled 128-byte rows of the first form cost ~10 VALU per read and were 2-way conflicted for 3 of 4 shifts);
@@ -1192,139 +943,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_p512(const bf16_raw* __restrict
 // free and immediate-addressed) which is prefetched one block ahead, and the nine taps of a block run without a
 // single barrier.  The result leaves through the shared staged epilogue.
 constexpr int C64_PITCH = 160;
-constexpr int C64_PATCH = 51 * 1024;                       // 324 px x 160 B = 51840 B -> 51 DMA instructions
-constexpr int C64_STAGE = 2 * C64_PATCH;                   // [256 px][64 ch] bf16 staging tile (32 KB)
-
-template <int EPI>
-__global__ __launch_bounds__(512) void k_conv3x3_c64(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ w, ConvGeom g,
-                                                     Epilogue ep, int tiles_x, int tiles_y) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_m = wave & 3, wave_n = wave >> 2;        // pixel rows 4 wave_m + p, channels 32 wave_n + 16 c
-    const int nblocks = g.B * tiles_x * tiles_y;
-    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (unsigned)g.B * g.H * g.W * 64u * 2u, 0x00020000);
-    constexpr unsigned OOB = 0xfffffff0u;
-
-    // patch DMA: instruction i = wave + 8j (j < 7, i < 51) fills 16-byte slots 64i..64i+63; slot q -> pixel q / 10, piece q % 10
-    // (pieces 8, 9 are the row padding).  The block origin enters through the pixel coordinates only: per-lane (py, px, piece)
-    int pcode[7];                                           // py << 16 | px << 8 | byte offset of the piece, -1 = padding
-#pragma unroll
-    for (int j = 0; j < 7; ++j) {
-        const int q = (wave + 8 * j) * 64 + lane;
-        const int pp = q / 10, sl = q - pp * 10;
-        const int py = pp / PATCH_W, px = pp - py * PATCH_W;
-        pcode[j] = (sl < 8 && pp < PATCH_PIX && wave + 8 * j < 51) ? ((py << 16) | (px << 8) | (sl * 16)) : -1;
-    }
-    auto issue_patch = [&](int t, int buf) {
-        int r = t;
-        const int tx = r % tiles_x; r /= tiles_x;
-        const int ty = r % tiles_y;
-        const int b = r / tiles_y;
-#pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            if (wave + 8 * j < 51) {
-                const int iy = ty * 16 - 1 + (pcode[j] >> 16), ix = tx * 16 - 1 + ((pcode[j] >> 8) & 255);
-                const bool ok = pcode[j] >= 0 && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
-                const unsigned off = (unsigned)((b * g.H + iy) * g.W + ix) * 128u + (unsigned)(pcode[j] & 255);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)(smem + buf * C64_PATCH + (wave + 8 * j) * 1024), 16,
-                                                         ok ? off : OOB, 0, 0, 0);
-            }
-        }
-    };
-    if ((int)blockIdx.x < nblocks) issue_patch(blockIdx.x, 0);
-
-    // weights -> registers: A fragment (tile c, tap, k-half ks): lane (row = lane & 15, fk = lane >> 4) holds
-    // w[32 wave_n + 16 c + row][tap][32 ks + 8 fk .. +7]   (w is [N][9][64]; rows >= N are zero)
-    const int frow = lane & 15, fk = lane >> 4;
-    bf16x8_t fw[2][9][2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int n = wave_n * 32 + c * 16 + frow;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (n < g.N) v = *reinterpret_cast<const uint4*>(w + (unsigned)n * 576u + (unsigned)(tap * 64 + ks * 32 + fk * 8));
-                fw[c][tap][ks] = *reinterpret_cast<const bf16x8_t*>(&v);
-            }
-    }
-    const int xbase = (4 * wave_m * PATCH_W + frow) * C64_PITCH + fk * 16;
-
-    int it = 0, prev_st = 0;
-    for (int t = blockIdx.x; t < nblocks; t += gridDim.x, ++it) {
-        const int cur = it & 1;
-        // this block's patch (issued one block ago) is older than the epilogue stores issued since: wait for all but
-        // those (prev_st = wave-uniform lower bound of the store instructions of the previous epilogue)
-        if (prev_st >= 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else if (prev_st == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-        else if (prev_st == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-        else if (prev_st == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + (int)gridDim.x < nblocks && !(g.ablate & 1)) issue_patch(t + gridDim.x, cur ^ 1);
-        int r = t;
-        const int tx = r % tiles_x; r /= tiles_x;
-        const int ty = r % tiles_y;
-        const int b = r / tiles_y;
-        const int y0 = ty * 16, x0 = tx * 16;
-        const int pb = cur * C64_PATCH + xbase;
-        f32x4_t acc[2][4];
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int p = 0; p < 4; ++p) acc[c][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8_t fx[4];
-#pragma unroll
-                for (int p = 0; p < 4; ++p)
-                    fx[p] = *reinterpret_cast<const bf16x8_t*>(smem + ((g.ablate & 4) ? xbase : pb + ((p + tap / 3) * PATCH_W + tap % 3) * C64_PITCH + ks * 64));
-                if (g.ablate & 32) {
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) asm volatile("" :: "v"(fx[p]));
-                } else {
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-#pragma unroll
-                    for (int p = 0; p < 4; ++p)
-                        acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[c][tap][ks], fx[p], acc[c][p], 0, 0, 0);
-                }
-                // 144 VGPRs hold the weights: keep the compiler from hoisting several steps of patch fragments on top of
-                // them (it spills otherwise); the partner wave on the SIMD covers the read latency
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        auto row_to_m = [&](int row) {
-            const int y = y0 + (row >> 4), xx = x0 + (row & 15);
-            return (y < g.Ho && xx < g.Wo) ? (b * g.Ho + y) * g.Wo + xx : -1;
-        };
-        auto pool_index = [&](int py, int px) -> long long {
-            const int gy = (y0 >> 1) + py, gx = (x0 >> 1) + px;
-            return (gy < ep.pool_h && gx < ep.pool_w) ? ((long long)b * ep.pool_h + gy) * ep.pool_w + gx : -1;
-        };
-        if (g.ablate & 8) {
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int p = 0; p < 4; ++p) asm volatile("" :: "v"(acc[c][p]));
-            prev_st = 0;
-            continue;
-        }
-        staged_epilogue<EPI, 256, 64, 2, 4, 512>(acc, smem + C64_STAGE, g, ep, 0, wave_m * 64, wave_n * 32, tid, row_to_m, pool_index);
-        // store instructions of that epilogue with at least one active lane (its loop: iteration i, wave w covers the
-        // 8 pixels x = 8 (w & 1) .. +7 of block row 4 i + (w >> 1))
-        prev_st = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) prev_st += (y0 + 4 * i + (wave >> 1) < g.Ho && x0 + 8 * (wave & 1) < g.Wo) ? 1 : 0;
-        if (EPI == EPI_FWD && !ep.out) prev_st = 0;          // pool-only: no full-resolution stores to leave in flight
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
-// The same layer, second form (default).  Timing the pieces of the kernel above on MI355X showed its
+// Timing the pieces of a first form of this kernel (16x16 blocks, one 8-wave workgroup per CU) on MI355X showed its
 // fragment reads (72 ds_read_b128 per wave and block = 4.6k LDS cycles per block at 128 B/clk) to cost as much as its
 // MFMAs (4.6k cycles) without overlapping them, and the epilogue (another 30 % of the time) to run with the matrix cores
 // idle because the CU holds a single workgroup.  Here
@@ -1797,202 +1418,6 @@ __global__ __launch_bounds__(WG) void k_conv_wgrad(const bf16_raw* __restrict__ 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int co = co0 + wave_m * 64 + a * 16 + (lane >> 4) * 4 + j;
-                if (co < g.N) ob[co] = accb[a][j];
-            }
-    }
-}
-
-// Weight gradient, LDS-DMA version with larger tiles: BMO output channels x BNC (tap,ci) columns per workgroup,
-// (BMO/64)x(BNC/64) waves of 64x64, 64 pixels per step, two LDS buffers, one barrier per step.  Tiles are
-// [pixel][channel] images written by global_load_lds (1 KiB per wave-instruction); the 32-byte column groups of
-// each pixel row are XOR-permuted by key(row) = (row&3) | ((row>>3)&1)<<2 so that the eight rows a half-wave
-// touches in one transposing read (ds_read_b64_tr_b16) fall on eight different bank groups.
-template <int BMO, int BNC, int AT>
-__global__ __launch_bounds__((BMO / (16 * AT)) * (BNC / 64) * 64) void k_conv_wgrad_dma(
-    const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ dy, float* __restrict__ slab_w,
-    float* __restrict__ slab_b, ConvGeom g, int m_per_split, int nsplit, int cout) {
-    constexpr int WAVES_M = BMO / (16 * AT), WAVES_N = BNC / 64, NW = WAVES_M * WAVES_N;   // wave tile: 16*AT channels x 64 columns
-    constexpr int RB_DY = BMO * 2, RB_X = BNC * 2;             // bytes per pixel row of each tile
-    constexpr int DYI = 64 * RB_DY / 1024 / NW;                 // dY DMA instructions per wave per step
-    constexpr int XI = 64 * RB_X / 1024 / NW;
-    static_assert(DYI >= 1 && XI >= 1, "tile too small for the wave count");
-    constexpr int KM_DY = RB_DY >= 256 ? 7 : RB_DY / 32 - 1;   // permutation stays inside the row's 32-byte groups
-    constexpr int KM_X = RB_X >= 256 ? 7 : RB_X / 32 - 1;
-    constexpr int T_DY = 64 * RB_DY, T_X = 64 * RB_X;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    auto s_dy = [&](int buf) { return smem + buf * (T_DY + T_X); };
-    auto s_x = [&](int buf) { return smem + buf * (T_DY + T_X) + T_DY; };
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_m = wave % WAVES_M, wave_n = wave / WAVES_M;
-    // XCD-aware order: all (column, channel) tiles of one pixel split run consecutively on ONE XCD (L % 8), so a
-    // split's dY / X rows stream through that XCD's L2 once and are shared by its tiles.
-    const int ktot = g.ldw;
-    const int ctiles = (ktot + BNC - 1) / BNC, mtiles = (cout + BMO - 1) / BMO, tiles = ctiles * mtiles;
-    const int kx = blockIdx.x >> 3;
-    const int split = (kx / tiles) * 8 + (blockIdx.x & 7);
-    if (split >= nsplit) return;
-    const int tile = kx % tiles;
-    const int bx = tile % ctiles, by = tile / ctiles;
-    const int col0 = bx * BNC, co0 = by * BMO;
-    const int m_begin = split * m_per_split;
-    const int m_end = min(g.M, m_begin + m_per_split);
-
-    // DMA ownership.  Instruction i (= wave + NW*j) of a tile covers bytes [1024 i, 1024 i + 1024): lane L writes the
-    // 16-byte slot at o = 1024 i + 16 L -> pixel row r = o / RB, physical chunk o % RB / 16; the logical chunk it must
-    // fetch undoes the group permutation.
-    int dy_r[DYI], dy_col[DYI];
-#pragma unroll
-    for (int j = 0; j < DYI; ++j) {
-        const int o = (wave + NW * j) * 1024 + lane * 16;
-        const int r = o / RB_DY, s16 = (o % RB_DY) >> 4;
-        const int key = ((r & 3) | (((r >> 3) & 1) << 2)) & KM_DY;
-        const int gl = ((s16 >> 1) & ~KM_DY) | (((s16 >> 1) & KM_DY) ^ key);
-        dy_r[j] = r;
-        const int co = co0 + (gl * 2 + (s16 & 1)) * 8;
-        dy_col[j] = co < g.N ? co : -1;
-    }
-    // X rows: flat pixel m = mstep + x_r[j] is tracked incrementally as (image base pixel, oy, ox)
-    int x_r[XI], x_cc[XI], x_kh[XI], x_kw[XI], x_b[XI], x_oy[XI], x_ox[XI];
-#pragma unroll
-    for (int j = 0; j < XI; ++j) {
-        {
-            const int o = (wave + NW * j) * 1024 + lane * 16;
-            const int m = min(m_begin + o / RB_X, g.M - 1);
-            const int b = fdiv(m, g.d_hw);
-            const int rem = m - b * g.d_hw.d;
-            x_oy[j] = fdiv(rem, g.d_w);
-            x_ox[j] = rem - x_oy[j] * g.d_w.d;
-            x_b[j] = b * g.H * g.W;
-        }
-        const int o = (wave + NW * j) * 1024 + lane * 16;
-        const int r = o / RB_X, s16 = (o % RB_X) >> 4;
-        const int key = ((r & 3) | (((r >> 3) & 1) << 2)) & KM_X;
-        const int gl = ((s16 >> 1) & ~KM_X) | (((s16 >> 1) & KM_X) ^ key);
-        const int q = (col0 >> 3) + gl * 2 + (s16 & 1);         // global 16-byte column chunk
-        x_r[j] = r;
-        if (q < g.nchunks) {
-            const int tap = q / g.cpt;
-            x_cc[j] = q - tap * g.cpt;
-            x_kh[j] = tap / g.KW;
-            x_kw[j] = tap - x_kh[j] * g.KW;
-        } else {
-            x_cc[j] = -1; x_kh[j] = 0; x_kw[j] = 0;
-        }
-    }
-    auto issue_dma = [&](int mstep, int buf) {
-#pragma unroll
-        for (int j = 0; j < DYI; ++j) {
-            const int m = mstep + dy_r[j];
-            const bf16_raw* src = (m < m_end && dy_col[j] >= 0) ? dy + ((unsigned)m * (unsigned)g.N + (unsigned)dy_col[j])
-                                                                : reinterpret_cast<const bf16_raw*>(g_zero16);
-            if (g.ablate & 8) src = dy + ((unsigned)mstep * (unsigned)g.N + (unsigned)((wave + NW * j) * 512 + lane * 8));
-            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(s_dy(buf) + (wave + NW * j) * 1024), 16, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < XI; ++j) {
-            const int m = mstep + x_r[j];
-            const int iy = x_oy[j] * g.mul - g.pad_t + x_kh[j], ix = x_ox[j] * g.mul - g.pad_l + x_kw[j];
-            const bool ok = m < m_end && x_cc[j] >= 0 && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
-            const unsigned off = (unsigned)(x_b[j] + iy * g.W + ix) * (unsigned)g.C + (unsigned)(x_cc[j] * 8);
-            const bf16_raw* src = ok ? x + off : reinterpret_cast<const bf16_raw*>(g_zero16);
-            if (g.ablate & 16) src = x + ((unsigned)mstep * (unsigned)g.C + (unsigned)((wave + NW * j) * 512 + lane * 8));
-            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(s_x(buf) + (wave + NW * j) * 1024), 16, 0, 0);
-            // advance this row by 64 output pixels for the next step
-            x_ox[j] += 64;
-            while (x_ox[j] >= g.Wo) {
-                x_ox[j] -= g.Wo;
-                if (++x_oy[j] == g.Ho) { x_oy[j] = 0; x_b[j] += g.H * g.W; }
-            }
-        }
-    };
-
-    f32x4_t acc[AT][4];
-    f32x4_t accb[AT];
-#pragma unroll
-    for (int a = 0; a < AT; ++a) {
-        accb[a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[a][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    }
-    const bool do_bias = slab_b != nullptr && bx == 0 && wave_n == 0;
-    bf16x8_t ones;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
-
-    const int nsteps = (m_end - m_begin + 63) / 64;
-    if (nsteps > 0) issue_dma(m_begin, 0);
-    const int gq = lane >> 4, li = lane & 15;
-    for (int st = 0; st < nsteps; ++st) {
-        const int cur = st & 1;
-        if (!(g.ablate & 2)) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-        if (st + 1 < nsteps && !(g.ablate & 1)) issue_dma(m_begin + (st + 1) * 64, cur ^ 1);
-#pragma unroll
-        for (int ksub = 0; ksub < 2; ++ksub) {
-            bf16x8_t fa[AT], fb[4];
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int krow = ksub * 32 + gq * 8 + half * 4 + (li >> 2);
-                const int key = (krow & 3) | (((krow >> 3) & 1) << 2);
-#pragma unroll
-                for (int a = 0; a < AT; ++a) {
-                    const int gl = (wave_m * (16 * AT) + a * 16) >> 4;               // 32-byte group of the tile column
-                    const int gp = (gl & ~KM_DY) | ((gl & KM_DY) ^ (key & KM_DY));
-                    const char* ptr = s_dy(cur) + krow * RB_DY + gp * 32 + (li & 3) * 8;
-                    const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(ptr));
-                    reinterpret_cast<s16x4_t*>(&fa[a])[half] = v;
-                }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int gl = (wave_n * 64 + c * 16) >> 4;
-                    const int gp = (gl & ~KM_X) | ((gl & KM_X) ^ (key & KM_X));
-                    const char* ptr = s_x(cur) + krow * RB_X + gp * 32 + (li & 3) * 8;
-                    const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(ptr));
-                    reinterpret_cast<s16x4_t*>(&fb[c])[half] = v;
-                }
-            }
-            if (g.ablate & 4) {
-#pragma unroll
-                for (int a = 0; a < AT; ++a) asm volatile("" ::"v"(fa[a]));
-#pragma unroll
-                for (int c = 0; c < 4; ++c) asm volatile("" ::"v"(fb[c]));
-            } else {
-#pragma unroll
-                for (int a = 0; a < AT; ++a)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[c], acc[a][c], 0, 0, 0);
-            }
-            if (do_bias) {
-#pragma unroll
-                for (int a = 0; a < AT; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], ones, accb[a], 0, 0, 0);
-            }
-        }
-    }
-    float* out = slab_w + (long long)split * g.N * ktot;
-#pragma unroll
-    for (int a = 0; a < AT; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int col = col0 + wave_n * 64 + c * 16 + (lane & 15);
-            if (col >= ktot) continue;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int co = co0 + wave_m * (16 * AT) + a * 16 + (lane >> 4) * 4 + j;
-                if (co < g.N) out[(long long)co * ktot + col] = acc[a][c][j];
-            }
-        }
-    if (do_bias && (lane & 15) == 0) {
-        float* ob = slab_b + (long long)split * g.N;
-#pragma unroll
-        for (int a = 0; a < AT; ++a)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int co = co0 + wave_m * (16 * AT) + a * 16 + (lane >> 4) * 4 + j;
                 if (co < g.N) ob[co] = accb[a][j];
             }
     }
@@ -2588,15 +2013,6 @@ __global__ __launch_bounds__(512) void k_conv0_wgrad(const bf16_raw* __restrict_
     }
 }
 
-// dW[i] = sum_z slab[z][i] in fixed order; also the bias gradient.
-__global__ void k_wgrad_reduce(const float* __restrict__ slab, long long n, int nsplit, float* __restrict__ out) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int z = 0; z < nsplit; ++z) s += slab[(long long)z * n + i];
-    out[i] = s;
-}
-
 // weights and bias in one launch: blocks [0, nbw) reduce the first nw elements of the weight slab (stride sw per split)
 // four at a time, the remaining blocks the nb bias elements (stride sb)
 __global__ __launch_bounds__(256) void k_wgrad_reduce2(const float* __restrict__ slab_w, long long sw, long long nw,
@@ -2921,10 +2337,10 @@ __global__ void k_head_grad_pack(const bf16_raw* __restrict__ dloc, const bf16_r
 // the caller's default applies), so concurrent calls are safe.
 struct Knob { const char* name; std::atomic<int> value; };
 constexpr int KNOB_UNSET = INT_MIN;
-Knob g_knobs[] = {{"SSD_ABLATE", {KNOB_UNSET}}, {"SSD_DGRAD_S2", {KNOB_UNSET}}, {"SSD_CONV_VARIANT", {KNOB_UNSET}},
+Knob g_knobs[] = {{"SSD_ABLATE", {KNOB_UNSET}}, {"SSD_DGRAD_S2", {KNOB_UNSET}}, 
                   {"SSD_CONV_PATCH", {KNOB_UNSET}}, {"SSD_CONV_TILE", {KNOB_UNSET}}, {"SSD_SPLITK", {KNOB_UNSET}},
-                  {"SSD_WGRAD_DMA", {KNOB_UNSET}}, {"SSD_WGRAD_PATCH", {KNOB_UNSET}}, {"SSD_WGRAD_PATCH_SINGLE", {KNOB_UNSET}},
-                  {"SSD_WGRAD_PATCH_SHAPE", {KNOB_UNSET}}, {"SSD_WGRAD_TILE", {KNOB_UNSET}}, {"SSD_CONV_PATCH_FORM", {KNOB_UNSET}},
+                  {"SSD_WGRAD_PATCH", {KNOB_UNSET}}, {"SSD_WGRAD_PATCH_SINGLE", {KNOB_UNSET}},
+                  {"SSD_WGRAD_PATCH_SHAPE", {KNOB_UNSET}}, {"SSD_WGRAD_TILE", {KNOB_UNSET}},
                   {"SSD_CONV_PATCH_FLAT", {KNOB_UNSET}}, {"SSD_WGRAD_FIRST", {KNOB_UNSET}}, {"SSD_CONV_FIRST", {KNOB_UNSET}},
                   {"SSD_WGRAD_PATCH_XCD", {KNOB_UNSET}}, {"SSD_CONV_C64", {KNOB_UNSET}}, {"SSD_CONV_POOL_FUSE", {KNOB_UNSET}},
                   {"SSD_CONV_PATCH_ROWFLAT", {KNOB_UNSET}}, {"SSD_MATCH_FUSED", {KNOB_UNSET}}, {"SSD_CONV_P512", {KNOB_UNSET}}};
@@ -2943,10 +2359,6 @@ int knob(const char* name, int dflt) {
 // the id at the launch site and returns instead of launching -- the query cannot drift from the dispatch.
 #define SSD_PLAN(ID_) do { if (plan) { *plan = (ID_); return SSD_OK; } } while (0)
 
-int igemm_variant() {                       // SSD_CONV_VARIANT=0: register-staged kernel, 1: LDS-DMA kernels, 2 (default): + 8-phase 256x256
-    return knob("SSD_CONV_VARIANT", 2);
-}
-
 template <int EPI>
 bool staged_ok_host(const ConvGeom& g, const Epilogue& ep) {
     if (ep.slab) return false;
@@ -2962,29 +2374,18 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
     Epilogue ep = ep_in;
     ep.slab = nullptr;
     ep.ksplit = 1;
-    const unsigned gm = (unsigned)((g.M + 127) / 128);
     if constexpr (EPI != EPI_HEAD) {
-        if (knob("SSD_CONV_C64", 2) && igemm_variant() >= 1 && g.KH == 3 && g.KW == 3 && g.mul == 1 && g.div == 1 && g.pad_t == 1 &&
+        if (knob("SSD_CONV_C64", 1) && g.KH == 3 && g.KW == 3 && g.mul == 1 && g.div == 1 && g.pad_t == 1 &&
             g.pad_l == 1 && g.C == 64 && g.N == 64 && g.ldw == 576 && g.H == g.Ho && g.W == g.Wo && g.H >= 16 && g.W >= 16 &&
             !ep.accumulate && !ep.up_out && (ep.ldo & 7) == 0 && (long long)g.B * g.H * g.W * 64 < (1ll << 31) - 16) {
             if (EPI == EPI_FWD && !ep.out && !(pooled && ep.pool_out)) return SSD_ERR_VALUE;
-            if (knob("SSD_CONV_C64", 2) >= 2) {             // 8 x 16 blocks, two workgroups per CU
-                const int tiles_x = (g.Wo + 15) / 16, tiles_y = (g.Ho + C64B_ROWS - 1) / C64B_ROWS;
-                const int nblocks = g.B * tiles_x * tiles_y;
-                auto kern = k_conv3x3_c64b<EPI>;
-                SSD_PLAN(SSD_PLAN_C64B | ((pooled && ep.pool_out) ? SSD_PLAN_F_POOL_FUSED : 0));
-                static OnceLds set; if (ensure_lds(set, reinterpret_cast<const void*>(kern), (int)(C64B_LDS)) != 0) return SSD_ERR_LAUNCH;
-                hipLaunchKernelGGL(kern, dim3((unsigned)(nblocks < 512 ? nblocks : 512)), dim3(256), C64B_LDS, s, xp, wp, g, ep, tiles_x, tiles_y);
-                if (pooled && ep.pool_out) *pooled = true;
-                return ssd_launch_status();
-            }
-            const int tiles_x = (g.Wo + 15) / 16, tiles_y = (g.Ho + 15) / 16;
+            // 8 x 16 blocks, two workgroups per CU
+            const int tiles_x = (g.Wo + 15) / 16, tiles_y = (g.Ho + C64B_ROWS - 1) / C64B_ROWS;
             const int nblocks = g.B * tiles_x * tiles_y;
-            constexpr int lds = 2 * C64_PATCH + 32768;
-            auto kern = k_conv3x3_c64<EPI>;
-            SSD_PLAN(SSD_PLAN_C64 | ((pooled && ep.pool_out) ? SSD_PLAN_F_POOL_FUSED : 0));
-            static OnceLds set; if (ensure_lds(set, reinterpret_cast<const void*>(kern), (int)(lds)) != 0) return SSD_ERR_LAUNCH;
-            hipLaunchKernelGGL(kern, dim3((unsigned)(nblocks < 256 ? nblocks : 256)), dim3(512), lds, s, xp, wp, g, ep, tiles_x, tiles_y);
+            auto kern = k_conv3x3_c64b<EPI>;
+            SSD_PLAN(SSD_PLAN_C64B | ((pooled && ep.pool_out) ? SSD_PLAN_F_POOL_FUSED : 0));
+            static OnceLds set; if (ensure_lds(set, reinterpret_cast<const void*>(kern), (int)(C64B_LDS)) != 0) return SSD_ERR_LAUNCH;
+            hipLaunchKernelGGL(kern, dim3((unsigned)(nblocks < 512 ? nblocks : 512)), dim3(256), C64B_LDS, s, xp, wp, g, ep, tiles_x, tiles_y);
             if (pooled && ep.pool_out) *pooled = true;
             return ssd_launch_status();
         }
@@ -2996,12 +2397,12 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
     // narrow maps (patch of 256 + 2 (W + 3) positions fits 32 KB): strip blocks, any channel count
     const int flat_knob = knob("SSD_CONV_PATCH_FLAT", 1);
     const bool use_flat = flat_knob && g.W <= 39 && g.W >= 16 && g.H >= 16 && (flat_knob >= 2 || !patch_fits || g.N > use_patch);
-    if (igemm_variant() >= 1 && g.KH == 3 && g.KW == 3 && g.mul == 1 && g.div == 1 && g.pad_t == 1 && g.pad_l == 1 &&
-        g.C % 64 == 0 && g.H == g.Ho && g.W == g.Wo && ((g.N <= use_patch && patch_fits) || use_flat) && g.H >= 16 && g.W >= 16) {
+    if (g.KH == 3 && g.KW == 3 && g.mul == 1 && g.div == 1 && g.pad_t == 1 && g.pad_l == 1 &&
+        g.C % 64 == 0 && g.H == g.Ho && g.W == g.Wo && ((g.N <= use_patch && patch_fits) || use_flat) && g.H >= 16 && g.W >= 16 &&
+        (long long)g.B * g.H * g.W * g.C < (1ll << 31) - 16 && (long long)g.N * g.ldw < (1ll << 31) - 16) {   // 31-bit buffer offsets
         const int tiles_x = (g.Wo + 15) / 16, tiles_y = (g.Ho + 15) / 16;
         const unsigned gx = (unsigned)(tiles_x * tiles_y * g.B);
-        if (knob("SSD_CONV_PATCH_FORM", 2) >= 2 && (long long)g.B * g.H * g.W * g.C < (1ll << 31) - 16 &&
-            (long long)g.N * g.ldw < (1ll << 31) - 16) {
+        {
             const bool flat = use_flat;
             // wide maps: one strip of rows over all images (k_conv3x3_patch32, "rowflat") when that needs fewer blocks and
             // the epilogue does not pool (2x2 windows would straddle blocks)
@@ -3055,26 +2456,10 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
             if (can_pool) *pooled = true;
             return ssd_launch_status();
         }
-        if (EPI == EPI_FWD && !ep.out) return SSD_ERR_VALUE;     // pool-only needs a pooling kernel
-        if (ep.up_out || ep.relu_bits || ep.mask_bits) return SSD_ERR_UNSUPPORTED;
-        if (g.N <= 64) {
-            const size_t lds = 2 * 64 * 128 + PATCH_BYTES;
-            auto kern = k_conv3x3_patch<64, EPI>;
-            SSD_PLAN(SSD_PLAN_PATCH_64);
-            static OnceLds set; if (ensure_lds(set, reinterpret_cast<const void*>(kern), (int)(2 * 64 * 128 + PATCH_BYTES)) != 0) return SSD_ERR_LAUNCH;
-            hipLaunchKernelGGL(kern, dim3(gx, (unsigned)((g.N + 63) / 64)), dim3(512), lds, s, xp, wp, g, ep, tiles_x, tiles_y);
-        } else {
-            const size_t lds = 2 * 128 * 128 + PATCH_BYTES;
-            auto kern = k_conv3x3_patch<128, EPI>;
-            SSD_PLAN(SSD_PLAN_PATCH_128);
-            static OnceLds set; if (ensure_lds(set, reinterpret_cast<const void*>(kern), (int)(2 * 128 * 128 + PATCH_BYTES)) != 0) return SSD_ERR_LAUNCH;
-            hipLaunchKernelGGL(kern, dim3(gx, (unsigned)((g.N + 127) / 128)), dim3(512), lds, s, xp, wp, g, ep, tiles_x, tiles_y);
-        }
-        return ssd_launch_status();
     }
     if (EPI == EPI_FWD && !ep.out) return SSD_ERR_VALUE;         // pool-only needs a pooling kernel
     if (ep.up_out) return SSD_ERR_UNSUPPORTED;                   // only the LDS-patch kernels un-pool in their epilogue
-    if (igemm_variant() >= 1) {
+    {
         // tile choice: the CU ingests ~28 B/clk from L2, so MACs per staged byte decide the ceiling: prefer the
         // largest tile that still gives every CU work (>= ~2 workgroups per CU), SSD_CONV_TILE overrides (testing)
         const int force = knob("SSD_CONV_TILE", 0);
@@ -3089,7 +2474,7 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
         else if (g.N > 64 && wg_256 * ((g.N + 127) / 128) >= 384) { bm = 256; bn = 128; }
         else if (g.N <= 64 && wg_256 >= 384) { bm = 256; bn = 64; }
         if (force == 1) { bm = 128; bn = g.N <= 64 ? 64 : 128; }
-        if (force == 2 && g.N > 128) { bm = 256; bn = 256; }
+        if ((force == 2 || force == 4) && g.N > 128) { bm = 256; bn = 256; }   // (4: the LDS-DMA kernel instead of the 8-phase one)
         if (force == 3 && g.N > 64) { bm = 256; bn = 128; }
         (void)wg_128;
         // split-K for skinny problems (few tiles, long k loop): partial sums to the caller's workspace
@@ -3125,7 +2510,7 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
             if (g.s2) { ntm_ = 0; for (int c_ = 0; c_ < 4; ++c_) ntm_ += (unsigned)((g.cls_n[c_] + BM_ - 1) / BM_); } \
             hipLaunchKernelGGL(kern_, dim3(8 * ntn_ * ((ntm_ + 7) / 8), ksplit), dim3(NT_), lds_, s, xp, wp, g, ep); \
         } while (0)
-        if (bm == 256 && bn == 256 && igemm_variant() >= 2 && !g.s2 && ksplit == 1 && g.cpt >= 8 &&
+        if (bm == 256 && bn == 256 && force != 4 && !g.s2 && ksplit == 1 && g.cpt >= 8 &&
             (long long)g.B * g.H * g.W * g.C < (1ll << 31) - 16 && (long long)g.N * g.ldw < (1ll << 31) - 16) {
             const unsigned ntm = (unsigned)((g.M + 255) / 256), ntn = (unsigned)((g.N + 255) / 256);
 #define SSD_LAUNCH_8PH(ABL_)                                                                                        \
@@ -3164,16 +2549,6 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
         }
         return ssd_launch_status();
     }
-    if (ep.relu_bits || ep.mask_bits) return SSD_ERR_UNSUPPORTED;
-    SSD_PLAN(g.N <= 64 ? SSD_PLAN_REG_64 : SSD_PLAN_REG_128);
-    if (g.N <= 64) {
-        const size_t lds = 2 * (128 + 64) * 128;
-        hipLaunchKernelGGL((k_conv_igemm<64, EPI>), dim3(gm, (unsigned)((g.N + 63) / 64)), dim3(WG), lds, s, xp, wp, g, ep);
-    } else {
-        const size_t lds = 2 * (128 + 128) * 128;
-        hipLaunchKernelGGL((k_conv_igemm<128, EPI>), dim3(gm, (unsigned)((g.N + 127) / 128)), dim3(WG), lds, s, xp, wp, g, ep);
-    }
-    return ssd_launch_status();
 }
 
 bool geom_ok(int B, int H, int W, int C, int Ho, int Wo, int N, int K) {
@@ -3327,10 +2702,6 @@ int ssd_conv2d_bwd_data(const void* dy, const void* w_t, const void* relu_src, v
                                 ws, ws_bytes, stream, nullptr);
 }
 
-static int wgrad_dma() {                    // SSD_WGRAD_DMA=1: LDS-DMA weight-gradient kernel (default: register-staged)
-    return knob("SSD_WGRAD_DMA", 0);
-}
-
 static int wgrad_patch_min_hw() {           // SSD_WGRAD_PATCH = smallest feature-map side served by the patch kernel (0: off)
     return knob("SSD_WGRAD_PATCH", 16);
 }
@@ -3390,9 +2761,8 @@ static void wgrad_patch_plan(int B, int Ho, int Wo, int Cin, int Cout, int* tile
 }
 
 static void wgrad_tiles(int Cout, long long ktot, int* bmo, int* bnc) {
-    *bmo = Cout > 128 ? 256 : (Cout > 64 ? 128 : 64);
-    *bnc = ktot > 128 ? 256 : 128;
-    if (!wgrad_dma()) { *bmo = 128; *bnc = 128; }
+    (void)Cout; (void)ktot;
+    *bmo = 128; *bnc = 128;
 }
 
 static int wgrad_splits(long long M, int tiles) {
@@ -3539,37 +2909,17 @@ static int conv2d_bwd_weight_impl(const void* x, const void* dy, float* dw, floa
     const int ns = wgrad_splits(g.M, ctiles * mtiles);
     int mps = (int)(((long long)g.M + ns - 1) / ns);
     mps = (mps + 63) / 64 * 64;
-    SSD_PLAN((wgrad_dma() ? SSD_PLAN_WG_DMA : SSD_PLAN_WG_GENERIC) | (ns >= 32 ? SSD_PLAN_F_REDUCE_WIDE : 0));
+    SSD_PLAN(SSD_PLAN_WG_GENERIC | (ns >= 32 ? SSD_PLAN_F_REDUCE_WIDE : 0));
     float* slab_w = static_cast<float*>(ws);
     float* slab_b = slab_w + (size_t)ns * ldy * ktot;
     hipStream_t s = (hipStream_t)stream;
     const bf16_raw* xp = static_cast<const bf16_raw*>(x);
     const bf16_raw* dyp = static_cast<const bf16_raw*>(dy);
     float* sb = dbias ? slab_b : nullptr;
-    if (!wgrad_dma()) {
+    {
         const size_t lds = 4 * 64 * WG_LD;
         static OnceLds attr_set; if (ensure_lds(attr_set, reinterpret_cast<const void*>(k_conv_wgrad), (int)((int)lds)) != 0) return SSD_ERR_LAUNCH;
         hipLaunchKernelGGL(k_conv_wgrad, dim3(ctiles, mtiles, ns), dim3(WG), lds, s, xp, dyp, slab_w, sb, g, mps);
-    } else {
-#define SSD_LAUNCH_WG(BMO_, BNC_)                                                                                  \
-        do {                                                                                                       \
-            constexpr int AT_ = BMO_ >= 256 ? 8 : 4;                                                               \
-            constexpr int NT_ = (BMO_ / (16 * AT_)) * (BNC_ / 64) * 64;                                            \
-            const size_t lds_ = 2 * 64 * (BMO_ + BNC_) * 2;                                                        \
-            auto kern_ = k_conv_wgrad_dma<BMO_, BNC_, AT_>;                                                        \
-            if (lds_ > 65536) {                                                                                    \
-                static OnceLds set_; if (ensure_lds(set_, reinterpret_cast<const void*>(kern_), (int)((int)lds_)) != 0) return SSD_ERR_LAUNCH; \
-            }                                                                                                      \
-            hipLaunchKernelGGL(kern_, dim3(8 * ctiles * mtiles * ((ns + 7) / 8)), dim3(NT_), lds_, s, xp, dyp, slab_w, \
-                               sb, g, mps, ns, Cout);                                                              \
-        } while (0)
-        if (bmo == 256 && bnc == 256) SSD_LAUNCH_WG(256, 256);
-        else if (bmo == 128 && bnc == 256) SSD_LAUNCH_WG(128, 256);
-        else if (bmo == 64 && bnc == 256) SSD_LAUNCH_WG(64, 256);
-        else if (bmo == 256) SSD_LAUNCH_WG(256, 128);
-        else if (bmo == 128) SSD_LAUNCH_WG(128, 128);
-        else SSD_LAUNCH_WG(64, 128);
-#undef SSD_LAUNCH_WG
     }
     if (hipGetLastError() != hipSuccess) return SSD_ERR_LAUNCH;
     launch_wgrad_reduce(s, slab_w, (long long)ldy * ktot, (long long)Cout * ktot, dw, slab_b, (long long)ldy, Cout, dbias, ns);
@@ -3629,20 +2979,15 @@ int ssd_conv2d_bwd_weight_plan(int B, int H, int W, int Cin, int Cout, int ldy, 
 const char* ssd_conv_plan_name(int plan) {
     switch (plan & SSD_PLAN_KERNEL_MASK) {
         case SSD_PLAN_C64B: return "k_conv3x3_c64b";
-        case SSD_PLAN_C64: return "k_conv3x3_c64";
         case SSD_PLAN_P32_64: return "k_conv3x3_patch32<64>";
         case SSD_PLAN_P32_128: return "k_conv3x3_patch32<128>";
         case SSD_PLAN_P512: return "k_conv3x3_p512";
-        case SSD_PLAN_PATCH_64: return "k_conv3x3_patch<64>";
-        case SSD_PLAN_PATCH_128: return "k_conv3x3_patch<128>";
         case SSD_PLAN_8PH: return "k_conv_igemm_8ph";
         case SSD_PLAN_DMA_256_256: return "k_conv_igemm_dma<256,256>";
         case SSD_PLAN_DMA_256_128: return "k_conv_igemm_dma<256,128>";
         case SSD_PLAN_DMA_256_64: return "k_conv_igemm_dma<256,64>";
         case SSD_PLAN_DMA_128_64: return "k_conv_igemm_dma<128,64>";
         case SSD_PLAN_DMA_128_128: return "k_conv_igemm_dma<128,128>";
-        case SSD_PLAN_REG_64: return "k_conv_igemm<64>";
-        case SSD_PLAN_REG_128: return "k_conv_igemm<128>";
         case SSD_PLAN_CONV0_FWD: return "k_conv0_fwd";
         case SSD_PLAN_WG_FIRST: return "k_conv0_wgrad";
         case SSD_PLAN_WG_PATCH_16x16: return "k_conv3x3_wgrad_patch<16,2>";
@@ -3650,7 +2995,6 @@ const char* ssd_conv_plan_name(int plan) {
         case SSD_PLAN_WG_PATCH_10x24: return "k_conv3x3_wgrad_patch<10,3>";
         case SSD_PLAN_WG_TILE: return "k_conv_wgrad_tile";
         case SSD_PLAN_WG_GENERIC: return "k_conv_wgrad";
-        case SSD_PLAN_WG_DMA: return "k_conv_wgrad_dma";
         default: return "?";
     }
 }

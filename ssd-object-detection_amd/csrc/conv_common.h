@@ -1,4 +1,4 @@
-// Types, geometry, epilogues and host helpers shared by the convolution translation units (conv.hip, wino.hip).
+// Types, geometry, epilogues and host helpers shared by the convolution translation units (conv.hip, sparse.hip, calib.hip).
 #pragma once
 #include <atomic>
 #include <type_traits>
@@ -504,7 +504,11 @@ inline ConvGeom make_geom(int B, int H, int W, int C, int Ho, int Wo, int N, int
     g.d_hw = make_fastdiv(Ho * Wo);
     g.d_w = make_fastdiv(Wo);
     g.d_h1 = make_fastdiv(H + 1);
+#ifdef SSD_DEV_ABLATE                        // timing-only ablations (they change results): development builds only
     g.ablate = ssd_knob("SSD_ABLATE", 0);
+#else
+    g.ablate = 0;
+#endif
     g.s2 = 0;
     const int s2on = ssd_knob("SSD_DGRAD_S2", 1);
     if (div == 2 && s2on && g.cpt % 8 == 0) {

@@ -365,6 +365,15 @@ __global__ __launch_bounds__(WG) void k_nms(const float* __restrict__ score, con
 
 }  // namespace
 
+// timing-only ablations of k_nms (they skip stages, i.e. change results): development builds only
+static int nms_ablate() {
+#ifdef SSD_DEV_ABLATE
+    return ssd_knob("SSD_ABLATE", 0);
+#else
+    return 0;
+#endif
+}
+
 extern "C" {
 
 int ssd_score_decode(const void* conf, const void* loc, int dtype, const double* priors, int B, int A, int C,
@@ -395,7 +404,7 @@ int ssd_nms(const float* score, const int32_t* cls, const float* box, const uint
     if (B <= 0 || A <= 0 || A > 65536 || max_cand <= 0 || max_cand > CAP) return SSD_ERR_VALUE;
     if (!score || !cls || !box || !cand || !keep) return SSD_ERR_VALUE;
     hipLaunchKernelGGL(k_nms, dim3(B), dim3(WG), 0, (hipStream_t)stream, score, cls, reinterpret_cast<const float4*>(box),
-                       cand, A, iou_thresh, max_cand, keep, keep_count, ssd_knob("SSD_ABLATE", 0));
+                       cand, A, iou_thresh, max_cand, keep, keep_count, nms_ablate());
     return ssd_launch_status();
 }
 

@@ -110,6 +110,11 @@ class SSDEngine:
         self.overlap_heads = os.environ.get("SSD_OVERLAP_HEADS", "1") != "0" and self.device.type == "cuda"
         self.step_count = 0
         self.skip_fullres = os.environ.get("SSD_SKIP_FULLRES", "1") == "1"   # pooled convs store the pooled map only
+        # schedule switches of the host program (read once, here): third stream for the small heads of the forward pass; dense
+        # head path only: the two large heads' backward on the side stream, their gradient packing there too
+        self.tail_stream = os.environ.get("SSD_TAIL_STREAM", "1") == "1"
+        self.big_heads_side = os.environ.get("SSD_BIG_HEADS_SIDE", "1") == "1"
+        self.pack_side = os.environ.get("SSD_PACK_SIDE", "1") == "1"
         self.pool_only = {}                    # node -> whether a pool-only kernel serves it (learned at the first call)
         self.fuse_unpool = {} if os.environ.get("SSD_FUSE_UNPOOL", "1") == "1" else None    # node -> data gradient un-pools itself
         # activation index -> its sign bits are written by the forward kernel (learned at the first call); data-gradient
@@ -149,8 +154,12 @@ class SSDEngine:
             nonlocal off
             numel = int(np.prod(shape))
             nb = (numel + self.block - 1) // self.block
+            # end-aligned: the tensor ENDS on a block boundary (the next one starts there: one contiguous GEMM operand over two
+            # optimizer variables); its start must stay 16-byte aligned in the bf16 copy too (DMA, float4)
             start = off + (nb * self.block - numel if end_aligned else 0)
-            assert start % 8 == 0                 # 16-byte aligned in the bf16 copy too (DMA, float4)
+            if start % 8:
+                raise ValueError("%s: %d elements do not end-align on a 16-byte boundary (per-cell anchor counts must make "
+                                 "n*4 a multiple of 8, i.e. even: the reference's are 4 and 6)" % (name, numel))
             t = ParamTensor(name, shape, start, len(self.tensors), off // self.block, nb)
             self.tensors.append(t)
             off += nb * self.block
@@ -312,7 +321,7 @@ class SSDEngine:
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.overlap_heads else None
         tail = None
-        if side is not None and os.environ.get("SSD_TAIL_STREAM", "1") == "1":
+        if side is not None and self.tail_stream:
             if getattr(self, "_tail", None) is None:
                 self._tail = torch.cuda.Stream(device=self.device)
                 self._ws_tail = ops.MatchWorkspace()
@@ -423,7 +432,16 @@ class SSDEngine:
             relu_src=[None if ub else acts[a] for a, ub in zip(idx, use_bits)])
         return hl, keep
 
-    def backward(self, dloc, dconf, on_ready=None, fused_adam=None, heads=None):
+    def bucket_gates(self, buckets):
+        """For tensor ranges [(t0, t1)] (the gradient exchange's buckets): the trunk node whose data gradient is the last
+        reader of the range's transposed weights (the lowest convolution in it), None for a range of head tensors only."""
+        gates = []
+        for t0, t1 in buckets:
+            nodes = [i for i, (wt, bt) in self.conv_params.items() if t0 <= wt.index < t1 or t0 <= bt.index < t1]
+            gates.append(min(nodes) if nodes else None)
+        return gates
+
+    def backward(self, dloc, dconf, on_ready=None, fused_adam=None, heads=None, on_dgrad=None):
         """Gradients of all parameters into self.grad (flat fp32) from d(loss)/d(loc), d(loss)/d(conf).
         on_ready([tensor indices]) is called right after the launches that complete those tensors' gradients (on the
         stream that runs them: an event recorded there covers them).
@@ -452,6 +470,8 @@ class SSDEngine:
 
         def opt_bucket(node):
             """Called once the data gradient of `node` (None: of every head) is enqueued on the main stream."""
+            if on_dgrad is not None:
+                on_dgrad(node)
             if node in opt_at:
                 t0, t1 = opt_at.pop(node)
                 on_side(lambda ws: self.adam_range(t0, t1, lr_t, hp["beta1"], hp["beta2"], hp["eps"], hp["clip"]), [])
@@ -486,7 +506,7 @@ class SSDEngine:
                 written[ni + 1] = True
             del keep
         big = [lvl for lvl, (ni, h, ch) in enumerate(self.fm) if heads is None and side is not None and B * h * h >= 16384
-               and os.environ.get("SSD_BIG_HEADS_SIDE", "1") == "1"]
+               and self.big_heads_side]
         head_done = {}                                     # activation index -> event after the head's data gradient
         packed = [None] * len(self.fm)
 
@@ -495,7 +515,7 @@ class SSDEngine:
             packed[lvl] = ops.head_grad_pack(dloc, dconf, h * h, self.num_priors[lvl], self.classes, self.head_npad[lvl],
                                              self.level_off[lvl], out=c["packed"][lvl]).view(B, h, h, self.head_npad[lvl])
 
-        pack_side = os.environ.get("SSD_PACK_SIDE", "1") == "1"
+        pack_side = self.pack_side
         for lvl in range(len(self.fm) if heads is None else 0):   # the large levels are packed where they are consumed (side stream)
             if lvl not in big or not pack_side:
                 pack(lvl)
@@ -689,12 +709,25 @@ class SSDEngine:
         self.refresh_weights()
 
     # ---------------------------------------------------------------- state
+    LAYOUT_VERSION = 2                         # 2: a level's loc / conf filters are separate variables (64 tensors for SSD300)
+
     def state_dict(self):
         return dict(param=self.param.cpu(), adam_m=self.adam_m.cpu(), adam_v=self.adam_v.cpu(), step=self.step_count,
                     names=[t.name for t in self.tensors], shapes=[t.shape for t in self.tensors],
-                    offsets=[t.offset for t in self.tensors])
+                    offsets=[t.offset for t in self.tensors], layout_version=self.LAYOUT_VERSION)
 
     def load_state_dict(self, sd):
+        """The flat buffers are only meaningful together with the layout they were saved under: names, shapes and offsets of
+        every variable must match this engine's (another class count, block size or an older fused-head layout would
+        otherwise load misaligned weights silently where the sizes happen to coincide)."""
+        mine = ([t.name for t in self.tensors], [tuple(t.shape) for t in self.tensors], [t.offset for t in self.tensors])
+        theirs = (list(sd.get("names", [])), [tuple(x) for x in sd.get("shapes", [])], list(sd.get("offsets", [])))
+        if sd.get("layout_version", 1) != self.LAYOUT_VERSION or mine != theirs or sd["param"].numel() != self.n_flat:
+            bad = [n for n in mine[0] if n not in theirs[0]][:3] + [n for n in theirs[0] if n not in mine[0]][:3]
+            raise ValueError("checkpoint parameter layout (version %s, %d variables, %d elements) does not match this engine's "
+                             "(version %d, %d variables, %d elements)%s" % (
+                                 sd.get("layout_version", 1), len(theirs[0]), sd["param"].numel(), self.LAYOUT_VERSION,
+                                 len(mine[0]), self.n_flat, "; e.g. " + ", ".join(bad) if bad else ""))
         self.param.copy_(sd["param"])
         self.adam_m.copy_(sd["adam_m"])
         self.adam_v.copy_(sd["adam_v"])

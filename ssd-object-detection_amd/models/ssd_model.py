@@ -231,17 +231,22 @@ class SSDObjectDetectionModel:
             _, info = self._ssd_loss((gt_cls[i:i + batch_step], gt_bbox[i:i + batch_step], gt_mask[i:i + batch_step]),
                                      (pred_loc, pred_conf), heads)
             if overlap:
-                self._reducer.begin()
-                eng.backward(info["dloc"], info["dconf"], on_ready=self._reducer.tensor_ready, heads=info["heads"])
-                post = None
-                if fused_dp:                           # Adam of a bucket right behind its all-reduce, on the comm stream
+                post = gates = None
+                if fused_dp:
+                    # Adam of a bucket on the communication stream right behind its all-reduce, as soon as the last data
+                    # gradient that reads the bucket's transposed weights is enqueued (engine.bucket_gates): the update of
+                    # all but the last bucket runs underneath the rest of the backward pass
                     eng.step_count = ssd_optimizer.iterations + 1
                     t = eng.step_count
                     lr = ssd_optimizer.lr()
                     b1, b2 = ssd_optimizer.beta_1, ssd_optimizer.beta_2
                     lr_t = lr * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
                     post = lambda t0, t1: eng.adam_range(t0, t1, lr_t, b1, b2, ssd_optimizer.epsilon, None, 1.0 / world)
-                self._reducer.finish(post)             # clipped per bucket, summed over ranks (RCCL over xGMI)
+                    gates = eng.bucket_gates(self._reducer.buckets)
+                self._reducer.begin(post, gates)
+                eng.backward(info["dloc"], info["dconf"], on_ready=self._reducer.tensor_ready, heads=info["heads"],
+                             on_dgrad=self._reducer.dgrad_done if fused_dp else None)
+                self._reducer.finish()                 # clipped per bucket, summed over ranks (RCCL over xGMI)
             elif fused:
                 eng.backward(info["dloc"], info["dconf"], fused_adam=fused_adam, heads=info["heads"])
             else:

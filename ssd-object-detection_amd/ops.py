@@ -74,15 +74,18 @@ def build_priors(grids=SSD300_GRIDS, s_ref=SSD300_S_REF, ratios=SSD300_RATIOS, i
     return prior_set_from(pri, make_grid(grids, ratios))
 
 
-def prior_set_from(priors, grid=None):
-    """Wrap an existing device f64 [A,4] prior array (any geometry)."""
+def prior_set_from(priors, grid=None, verify=False):
+    """Wrap an existing device f64 [A,4] prior array (any geometry).  verify=True also checks `grid` against the array on the
+    device (PriorSet.verify_grid: one launch + one host synchronisation) -- only the opt-in single-launch matcher needs a
+    verified grid, so the default construction neither launches nor synchronises for it."""
     L = _lib.lib()
     priors = _dev(priors, torch.float64)
     A = priors.shape[0]
     enc0 = torch.empty((A, 4), dtype=torch.float32, device=priors.device)
     _lib.check(L.ssd_encode_zero(_ptr(priors), A, _ptr(enc0), _stream()))
     ps = PriorSet(priors, enc0, grid)
-    ps.verify_grid()
+    if verify:
+        ps.verify_grid()
     return ps
 
 
@@ -502,65 +505,6 @@ def conv2d_bwd_data_unpool(dy, w_t, relu_src, pool_code, full_shape, out=None, w
     if rc == _lib.SSD_ERR_UNSUPPORTED:
         raise NotImplementedError("no LDS-patch kernel for this layer")
     _lib.check(rc)
-    return out
-
-
-def wino_supported(B, H, W, Cin, Cout):
-    """Shapes served by the Winograd F(2x2,3x3) kernels (3x3 / stride 1 / pad 1 only)."""
-    return bool(_lib.lib().ssd_conv3x3_wino_supported(B, H, W, Cin, Cout))
-
-
-def wino_weights(w, w_shift=0, out=None):
-    """Transformed weights G g G^T (fp16, MFMA fragment order) of w[Cout][3][3][Cin]; for the data gradient pass
-    weight_transpose(w) (its leading dimension is then Cin)."""
-    L = _lib.lib()
-    _bf(w)
-    Cout, k, _, Cin = w.shape
-    assert k == 3 and w.shape[2] == 3
-    if out is None:
-        out = torch.empty(L.ssd_wino_weights_bytes(Cout, Cin) // 2, dtype=torch.float16, device=w.device)
-    assert out.dtype == torch.float16 and out.numel() == 16 * Cout * Cin and out.is_contiguous()
-    _lib.check(L.ssd_wino_weights(_ptr(w), _ptr(out), Cout, Cin, w_shift, _stream()))
-    return out
-
-
-def conv3x3_wino_fwd(x, u, bias, Cout, relu, out=None, pool=None, pool_out=None, code=None, pool_only=False, in_shift=0,
-                     w_shift=0):
-    """3x3 / stride 1 / pad 1 convolution (+bias, +ReLU) through the Winograd kernel.  pool: None, or "same" / "valid" for
-    the fused 2x2 / stride-2 max pooling (returns out, pool_out, code like conv2d_fwd_pool)."""
-    L = _lib.lib()
-    _bf(x)
-    B, H, W, Cin = x.shape
-    assert u.dtype == torch.float16 and u.numel() == 16 * Cout * Cin
-    if pool_only:
-        assert pool is not None
-        out = None
-    elif out is None:
-        out = torch.empty((B, H, W, Cout), dtype=torch.bfloat16, device=x.device)
-    Hp = Wp = 0
-    if pool is not None:
-        Hp, Wp = ((H + 1) // 2, (W + 1) // 2) if pool == "same" else (H // 2, W // 2)
-        if pool_out is None:
-            pool_out = torch.empty((B, Hp, Wp, Cout), dtype=torch.bfloat16, device=x.device)
-        if code is None:
-            code = torch.empty((B, Hp, Wp, Cout // 8), dtype=torch.int32, device=x.device)
-    _lib.check(L.ssd_conv3x3_wino_fwd(_ptr(x), _ptr(u), _ptr(bias), _ptr(out), _ptr(pool_out) if pool is not None else None,
-                                      _ptr(code) if pool is not None else None, B, H, W, Cin, Cout, 1 if relu else 0, Hp, Wp,
-                                      in_shift, w_shift, _stream()))
-    return out if pool is None else (out, pool_out, code)
-
-
-def conv3x3_wino_bwd_data(dy, u_t, relu_src, x_shape, accumulate=False, out=None, in_shift=0, w_shift=0):
-    L = _lib.lib()
-    _bf(dy)
-    B, H, W, Cin = x_shape
-    Cout = dy.shape[3]
-    assert dy.shape == (B, H, W, Cout) and u_t.dtype == torch.float16 and u_t.numel() == 16 * Cout * Cin
-    if out is None:
-        assert not accumulate
-        out = torch.empty(x_shape, dtype=torch.bfloat16, device=dy.device)
-    _lib.check(L.ssd_conv3x3_wino_bwd_data(_ptr(dy), _ptr(u_t), _ptr(relu_src), _ptr(out), B, H, W, Cin, Cout,
-                                           1 if accumulate else 0, in_shift, w_shift, _stream()))
     return out
 
 

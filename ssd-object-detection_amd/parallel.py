@@ -54,11 +54,20 @@ class GradReducer:
         self._events = []
         self.begin()
 
-    def begin(self):
+    def begin(self, post_fn=None, gates=None):
+        """Start a step.  post_fn(t0, t1) (optional): the optimizer step of a bucket, run on the communication stream right
+        behind the bucket's all-reduce.  gates[k]: the bucket may only be updated once the data gradient of trunk node
+        gates[k] has been enqueued (it is the last reader of the bucket's transposed weights; None: the heads' data
+        gradient); the backward pass reports those through dgrad_done().  Without gates the updates run in finish()."""
         self.ready = [False] * len(self.offsets)
         self.next_bucket = 0
         self.handles = []
         self._events = []
+        self.post_fn = post_fn
+        self.gates = list(gates) if gates is not None else None
+        assert self.gates is None or len(self.gates) == len(self.buckets)
+        self.next_post = 0
+        self._last_dgrad = "none"              # "none": nothing reported yet; None: heads; int: lowest trunk node so far
 
     def _mark_done(self, k):
         if self.profile and k < len(self._events):
@@ -105,11 +114,56 @@ class GradReducer:
             self.clip_fn(t0, t1)
             self.handles.append(dist.all_reduce(view, group=self.group, async_op=True))
 
+    def _gate_open(self, gate):
+        if self._last_dgrad == "none":
+            return False
+        if gate is None:
+            return True
+        return self._last_dgrad is not None and self._last_dgrad <= gate
+
+    def dgrad_done(self, node):
+        """The backward pass has just enqueued (on the current stream) the data gradient of trunk node `node` (None: of the
+        heads).  Every launched bucket whose gate this opens gets its update enqueued on the communication stream: behind
+        its own all-reduce and behind that data gradient -- while the rest of the backward pass is still running."""
+        self._last_dgrad = node if (node is None or self._last_dgrad in ("none", None)) else min(self._last_dgrad, node)
+        self._post_ready()
+
+    def _post_ready(self):
+        if self.post_fn is None or self.gates is None:
+            return
+        ev = None
+        while self.next_post < self.next_bucket and self._gate_open(self.gates[self.next_post]):
+            k = self.next_post
+            t0, t1 = self.buckets[k]
+            if self.use_streams:
+                if ev is None:
+                    ev = torch.cuda.Event()
+                    ev.record()                               # the gating data gradient is enqueued on the caller's stream
+                with torch.cuda.stream(self.comm):
+                    self.comm.wait_event(ev)
+                    self.handles[k].wait()
+                    self._mark_done(k)
+                    self.post_fn(t0, t1)
+            else:
+                self.handles[k].wait()
+                self.post_fn(t0, t1)
+            self.next_post += 1
+
     def finish(self, post_fn=None):
         """Wait for the exchange.  post_fn(t0, t1), if given, is run for every bucket right behind its all-reduce (on the
         communication stream, once everything the caller has enqueued so far is done): the optimizer step of a bucket
         then overlaps the all-reduce of the next ones instead of waiting for the last."""
         assert self.next_bucket == len(self.buckets), "backward did not report every tensor"
+        if self.post_fn is not None and self.gates is not None:
+            # per-bucket updates: whatever the gates have not released yet (nothing, when the backward pass reported every
+            # data gradient) runs now, behind the whole backward pass
+            self._last_dgrad = -1
+            self._post_ready()
+            assert self.next_post == len(self.buckets)
+            if self.use_streams:
+                torch.cuda.current_stream().wait_stream(self.comm)
+            self.handles = []
+            return
         if post_fn is not None and self.use_streams:
             ev = torch.cuda.Event()
             ev.record()                                   # the caller's stream: the whole backward pass is enqueued

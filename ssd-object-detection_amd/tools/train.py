@@ -56,9 +56,12 @@ def _init_distributed():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1:
         return 0, 1
-    backend = os.environ.get("SSD_DIST_BACKEND", "nccl")
+    # RCCL needs one GPU per rank; with fewer GPUs than ranks (a one-GPU box rehearsing the multi-rank path) ranks share a
+    # device and the exchange goes over gloo (the rule of bench.py)
+    n_dev = torch.cuda.device_count()
+    backend = os.environ.get("SSD_DIST_BACKEND", "nccl" if n_dev >= world else "gloo")
     if torch.cuda.is_available():
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % n_dev)
     if not torch.distributed.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group(backend)

@@ -253,6 +253,40 @@ def test_p512_equals_patch32_at_layer_size(ops, case):
         assert torch.equal(a, b)
 
 
+def test_p512_row_strip_full_size_vs_fp32_oracle(ops):
+    """The most-used launch of k_conv3x3_p512 -- block3_conv2/3 at batch 64: 75 x 75 x 256 -> 256 as one strip of rows over
+    all images -- directly against the fp32 reference at that size: forward (+bias, ReLU) and the masked, accumulating data
+    gradient.  (test_p512_equals_patch32_at_layer_size ties p512 to patch32 bit for bit; this closes the chain to the oracle
+    at the size that runs.)"""
+    from ssd_object_detection_amd import _lib
+    from tests.conv_cases import plan_name
+    B, H, W, Cin, Cout = 64, 75, 75, 256, 256
+    L = _lib.lib()
+    assert plan_name(L, L.ssd_conv2d_fwd_plan(B, H, W, Cin, Cout, 3, 1, 1, 1, H, W, 0, 1 << 25)) == "k_conv3x3_p512+rowflat"
+    assert plan_name(L, L.ssd_conv2d_bwd_data_plan(B, H, W, Cin, Cout, 3, 1, 1, 1, H, W, 1, 1 << 25)) == "k_conv3x3_p512+rowflat"
+    g = torch.Generator().manual_seed(75)
+    x = torch.randn((B, H, W, Cin), generator=g).relu().bfloat16()
+    w = (torch.randn((Cout, 3, 3, Cin), generator=g) / np.sqrt(9 * Cin)).bfloat16()
+    bias = torch.randn((Cout,), generator=g) * 0.1
+    dy = torch.randn((B, H, W, Cout), generator=g).bfloat16()
+    base = torch.randn((B, H, W, Cin), generator=g).bfloat16()
+    xd, wd = x.cuda(), w.cuda()
+    y = ops.conv2d_fwd(xd, wd, bias.cuda(), 1, 1, 1, H, W, True).float().cpu()
+    acc = base.clone().cuda()
+    ops.conv2d_bwd_data(dy.cuda(), ops.weight_transpose(wd), xd, (B, H, W, Cin), 1, 1, 1, accumulate=True, out=acc)
+    acc = acc.float().cpu()
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    with torch.no_grad():
+        yr = ref_conv(x.float(), w.float(), bias, 3, 1, 1, 1, H, W, True)
+        assert (y - yr).abs().max().item() <= 2 ** -7 * max(1.0, yr.abs().max().item())
+        del yr, y
+        # data gradient of a 3x3 / stride 1 / pad 1 convolution = the convolution of dy with the flipped, transposed filters
+        wt = w.float().flip(1, 2).permute(3, 1, 2, 0).contiguous()                  # [Cin, 3, 3, Cout]
+        dxr = ref_conv(dy.float(), wt, None, 3, 1, 1, 1, H, W, False)
+        want = (dxr + base.float()) * (x.float() > 0)
+    assert (acc - want).abs().max().item() <= 2 ** -6 * max(1.0, want.abs().max().item())
+
+
 @pytest.mark.parametrize("shape", [0, 1, 2])
 def test_wgrad_patch_block_shapes(ops, shape):
     """Every block shape of the LDS-patch weight-gradient kernel (16x16, 6x40, 10x24) gives the same gradient;

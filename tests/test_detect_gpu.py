@@ -117,3 +117,32 @@ def test_nms_argument_checks(ops, pset):
     z = torch.zeros((1, 16), device="cuda")
     with pytest.raises(ValueError):
         ops.nms(z, z.int(), torch.zeros((1, 16, 4), device="cuda"), z.to(torch.uint8), 0.45, 4096)
+
+
+def test_eval_pass_at_batch_64_vs_c_oracle(ops, pset):
+    """BASELINE configs[2]'s "NMS eval pass" at its full batch (64 images, the bench's input construction): scores within the
+    float tolerance of the f64 oracle, candidate sets equal away from the threshold, and the keep mask of EVERY image
+    bit-exact against the C restatement of the build-defined NMS (oracle/ssd_oracle.c) on the device's own candidates."""
+    from oracle import c_oracle
+    B, A, C = 64, 8732, 81
+    conf_np, loc_np = synth_logits(B, A, C, 320, 64)
+    conf, loc = torch.from_numpy(conf_np).cuda(), torch.from_numpy(loc_np).cuda()
+    score, cls, box, cand = ops.score_decode(conf, loc, pset, 0.3)
+    keep, count = ops.nms(score, cls, box, cand, 0.45, 400, want_count=True)
+    s, c, bx, cd = score.cpu().numpy(), cls.cpu().numpy(), box.cpu().numpy(), cand.cpu().numpy()
+    keep, count = keep.cpu().numpy().astype(bool), count.cpu().numpy()
+    s_ref, c_ref, cand_ref = O.score(conf_np, 0.3)
+    np.testing.assert_allclose(s, s_ref, rtol=2e-6, atol=1e-9)
+    p_bg = np.exp(O._log_softmax(conf_np))[..., -1]
+    border = (np.abs(s_ref - 0.3) < 1e-6) | (np.abs(p_bg - 0.3) < 1e-6)
+    assert np.array_equal(cd.astype(bool)[~border], cand_ref[~border])
+    pri = pset.priors.cpu().numpy()
+    want_box = O.decode(loc_np, pri[None], 300)
+    np.testing.assert_allclose(bx[cd.astype(bool)], want_box[cd.astype(bool)], rtol=3e-7, atol=0)
+    n_c = cd.sum(1)
+    assert (n_c > 150).all() and (n_c < 1024).all()
+    for b in range(B):
+        want = c_oracle.nms(s[b], c[b], bx[b], cd[b], 0.45, 400)
+        assert np.array_equal(keep[b], want), "image %d: %d vs %d kept" % (b, keep[b].sum(), want.sum())
+        assert int(count[b]) == int(want.sum())
+    assert (keep.sum(1) < np.minimum(n_c, 400)).any()        # suppression happened

@@ -209,7 +209,7 @@ def test_single_launch_path_equals_three_launch_path(ops, pset):
     from ssd_object_detection_amd.data_loaders.synthetic import synth_batch_gt
     from tests.test_cfg5_gpu import _conflict_heavy
     L = _lib.lib()
-    assert pset.grid.verified != 0
+    assert pset.verify_grid() is True                          # explicit: the default construction does not verify
     rng = np.random.default_rng(12)
     try:
         for it, (B, nt) in enumerate([(64, None), (256, None), (700, None), (64, 64), (33, 40), (9, 57), (512, None), (128, 17), (40, -1)]):

@@ -260,3 +260,21 @@ def test_bucketed_optimizer_and_async_targets_are_bitwise_neutral(tmp_path):
     assert len(b.opt_buckets()) >= 4 and b.opt_buckets()[0][2] is None
     covered = sorted(t for t0, t1, _ in b.opt_buckets() for t in range(t0, t1))
     assert covered == list(range(len(b.tensors)))
+
+
+def test_checkpoint_layout_is_checked_on_load(tmp_path):
+    """A checkpoint's flat buffers only mean something under the variable layout they were saved with: a state dict whose
+    names / offsets / layout version differ is refused with a ValueError instead of loading misaligned weights."""
+    from ssd_object_detection_amd.engine import SSDEngine
+    eng = SSDEngine(classes=81, seed=1)
+    sd = eng.state_dict()
+    eng.load_state_dict(sd)                                   # its own layout loads
+    old = dict(sd, layout_version=1)
+    with pytest.raises(ValueError):
+        eng.load_state_dict(old)
+    fused = dict(sd, names=[n.replace("loc_kernel", "kernel") for n in sd["names"]])
+    with pytest.raises(ValueError):
+        eng.load_state_dict(fused)
+    shifted = dict(sd, offsets=[o + (8 if i == 5 else 0) for i, o in enumerate(sd["offsets"])])
+    with pytest.raises(ValueError):
+        eng.load_state_dict(shifted)

@@ -366,7 +366,8 @@ def kernel_sections(np, torch, ops, model, eng, pset, batches, match_out, B, res
     # the nominal dense bf16 peak and against what this device sustained for the same instruction mix in this run.
     result["roofline"] = dict(
         dom, bound="mfma", peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(dom["achieved"] / PEAK_BF16_TFLOPS, 4),
-        frac_of_calibration=round(dom["achieved"] / cal["tflops"], 4), traffic=(conv_pmc or {}).get("dominant_kernel_hbm_bytes_per_launch"),
+        frac_of_calibration=round(dom["achieved"] / cal["tflops"], 4), traffic=(conv_pmc or {}).get("dominant_kernel_hbm_bytes_per_step"),
+        traffic_note="HBM bytes of the kernel's launches of one step (PMC); algorithmic: each layer's x and dy read once = %d" % dom["algorithmic_bytes"],
         traffic_source=conv_pmc_file, traffic_commit=(conv_pmc or {}).get("commit"),
         aggregate={"kernel": "all convolution launches of one step (forward + backward, two streams)",
                    "achieved": round(agg, 2), "frac": round(agg / PEAK_BF16_TFLOPS, 4),
@@ -443,7 +444,7 @@ def dominant_kernel(torch, ops, eng, B):
     L = _lib.lib()
     c = eng._acts(B)
     want = None
-    layers, flops, secs = [], 0.0, 0.0
+    layers, flops, secs, abytes = [], 0.0, 0.0, 0
     for i, nd in enumerate(eng.nodes):
         if nd["kind"] != "conv":
             continue
@@ -461,10 +462,11 @@ def dominant_kernel(torch, ops, eng, B):
                                                       dw=eng.view(wt, eng.grad), dbias=eng.view(bt, eng.grad), ws=eng._ws), 5)
         layers.append("conv%d" % i)
         secs += t
+        abytes += 2 * B * (nd["hin"] * nd["hin"] * nd["cin"] + nd["hout"] * nd["hout"] * nd["cout"]) + 4 * nd["cout"] * 9 * nd["cin"]
         flops += 2.0 * B * nd["hout"] * nd["hout"] * nd["cout"] * 9 * nd["cin"]
     return {"kernel": "%s (weight gradients of %s)" % (want, ", ".join(layers)),
             "launches_per_step": len(layers), "us_per_step": round(secs * 1e6, 1), "achieved": round(flops / secs / 1e12, 2),
-            "flops": flops}
+            "flops": flops, "algorithmic_bytes": abytes}
 
 
 def config2_section(torch, ops, pset):

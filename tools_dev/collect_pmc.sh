@@ -4,7 +4,7 @@
 #   mfma:  SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES per convolution kernel
 #   match: FETCH_SIZE / WRITE_SIZE of the matching kernels at batch 64
 # Counters are collected with --kernel-trace only (never with the trace domains gpurun refuses next to --pmc).
-# usage: tools_dev/collect_pmc.sh <commit-hash> <out-prefix, e.g. profiles/r02>
+# usage: tools_dev/collect_pmc.sh <commit-hash> <out-prefix, e.g. profiles/r03>
 set -e
 COMMIT=$1; OUT=$2
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"

@@ -23,7 +23,8 @@ def last_step(rs):
     return [x for x in rs if adam[-2] < int(x["Dispatch_Id"]) <= adam[-1]]
 
 
-conv = lambda n: n.startswith(("k_conv", "k_wgrad", "k_igemm"))
+conv = lambda n: n.startswith(("k_conv", "k_wgrad", "k_igemm", "k_hz_", "k_hw_"))      # incl. the sparse head backward
+DOMINANT = "k_conv3x3_wgrad_patch<16, 2>"                                             # bench.py's roofline.kernel
 
 # ---- convolution traffic of one step
 fetch, write = collections.OrderedDict(), collections.OrderedDict()
@@ -37,6 +38,11 @@ c = {"commit": commit, "workload": "one batch-64 train step, single stream (tool
      "per_kernel_fetch_kb": {k: round(v, 1) for k, v in fetch.items() if conv(k)},
      "per_kernel_write_kb": {k: round(v, 1) for k, v in write.items() if conv(k)}}
 c["conv_hbm_bytes_per_step"] = int((2 * c["conv_fetch_kb"] + c["conv_write_kb"]) * 1024)
+n_dom = len({x["Dispatch_Id"] for x in last_step(rows("conv_fetch", {"FETCH_SIZE"})) if short(x["Kernel_Name"]) == DOMINANT})
+if n_dom:
+    c["dominant_kernel"] = DOMINANT
+    c["dominant_kernel_launches_per_step"] = n_dom
+    c["dominant_kernel_hbm_bytes_per_step"] = int((2 * fetch.get(DOMINANT, 0.0) + write.get(DOMINANT, 0.0)) * 1024)
 json.dump(c, open(out + "_conv_pmc.json", "w"), indent=1)
 
 # ---- MFMA utilisation per convolution kernel (one step)

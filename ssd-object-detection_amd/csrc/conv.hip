@@ -626,11 +626,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int wdst = wave < BN / 16 ? wave * 1024 : -1;     // -1: dummy
     const int nchunk = g.C >> 5;
 
+    // The kernel runs at the 128-register limit of four waves per SIMD, and the compiler kept three of the four patch offsets
+    // in scratch, re-loading each one right in front of its DMA: "wait for the reload" is s_waitcnt vmcnt(0), which also waits
+    // for the patch DMA issued just before to LAND -- the four requests of a chunk went out one memory round trip apart.
+    // Here the three offsets are parked in scratch on purpose and fetched TOGETHER ahead of the first request of a chunk
+    // (they are only needed once per chunk, when the fragment registers are free): one round trip, four requests back to back.
+    unsigned pstash[3];
+    pstash[0] = pvo[1]; pstash[1] = pvo[2]; pstash[2] = pvo[3];
+    asm volatile("" ::"v"(&pstash[0]) : "memory");          // the address escapes: the array stays in (scratch) memory
+    const unsigned pvo0 = pvo[0];
     auto dma_patch = [&](int chunk, int buf) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)(smem + buf * P32_PATCH + (wave + 8 * j) * 1024), 16, pvo[j],
-                                                     chunk * 64, 0, 0);
+        const unsigned o1 = pstash[0], o2 = pstash[1], o3 = pstash[2];
+        char* dst = smem + buf * P32_PATCH + wave * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)dst, 16, pvo0, chunk * 64, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)(dst + 8 * 1024), 16, o1, chunk * 64, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)(dst + 16 * 1024), 16, o2, chunk * 64, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)(dst + 24 * 1024), 16, o3, chunk * 64, 0, 0);
     };
     auto dma_w = [&](int chunk, int tap, int buf) {
         char* dst = wdst >= 0 ? smem + OFF_W + buf * WBYTES + wdst : smem + OFF_DUMMY;

@@ -22,17 +22,19 @@ __device__ __forceinline__ void stage_block(const T* __restrict__ src, size_t co
     const uint4* v = reinterpret_cast<const uint4*>(src);
     for (size_t base = 0; base < nvec; base += (size_t)STAGE_DEPTH * RB_WG) {
         uint4 raw[STAGE_DEPTH];
+        const size_t last = nvec ? nvec - 1 : 0;
 #pragma unroll
         for (int j = 0; j < STAGE_DEPTH; ++j) {
             const size_t i = base + (size_t)j * RB_WG + threadIdx.x;
-            if (i < nvec) raw[j] = v[i];
+            raw[j] = v[i < last ? i : last];               // unconditional: keeps `raw` in registers, the loads in flight together
         }
 #pragma unroll
         for (int j = 0; j < STAGE_DEPTH; ++j) {
             const size_t i = base + (size_t)j * RB_WG + threadIdx.x;
             if (i >= nvec) continue;
             if constexpr (sizeof(T) == 4) {
-                *reinterpret_cast<uint4*>(lds + i * 4) = raw[j];
+                *reinterpret_cast<float4*>(lds + i * 4) = make_float4(__uint_as_float(raw[j].x), __uint_as_float(raw[j].y),
+                                                                      __uint_as_float(raw[j].z), __uint_as_float(raw[j].w));
             } else {
                 const unsigned w[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
                 float f[8];
@@ -53,15 +55,19 @@ __device__ __forceinline__ void stage_block(const T* __restrict__ src, size_t co
 // The same staging split in two, for a loop that requests the NEXT block's elements (stage_load) before it computes on the
 // current one and writes them to LDS (stage_store) after the following barrier: the global loads are in flight during the
 // computation.  NV = ceil(count / (16 / sizeof(T)) / RB_WG) registers of 16 bytes per lane.
+// Every lane loads unconditionally (a lane past the end re-reads the last chunk, which stage_store then ignores): with a
+// conditional assignment the compiler keeps `raw` in scratch memory and waits for each load before it issues the next one --
+// eleven serialised memory round trips per block instead of eleven loads in flight (k_score_decode: 94 us -> see DESIGN.md).
 template <typename T, int NV>
 __device__ __forceinline__ void stage_load(const T* __restrict__ src, size_t count, uint4 (&raw)[NV]) {
     constexpr int PER = 16 / sizeof(T);
     const size_t nvec = count / PER;
     const uint4* v = reinterpret_cast<const uint4*>(src);
+    const size_t last = nvec ? nvec - 1 : 0;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const size_t i = (size_t)j * RB_WG + threadIdx.x;
-        if (i < nvec) raw[j] = v[i];
+        raw[j] = v[i < last ? i : last];
     }
 }
 
@@ -74,7 +80,9 @@ __device__ __forceinline__ void stage_store(const T* __restrict__ src, size_t co
         const size_t i = (size_t)j * RB_WG + threadIdx.x;
         if (i >= nvec) continue;
         if constexpr (sizeof(T) == 4) {
-            *reinterpret_cast<uint4*>(lds + i * 4) = raw[j];
+            // (component-wise: a whole-uint4 copy out of `raw` is lowered as a memory copy and pins the array in scratch)
+            *reinterpret_cast<float4*>(lds + i * 4) = make_float4(__uint_as_float(raw[j].x), __uint_as_float(raw[j].y),
+                                                                  __uint_as_float(raw[j].z), __uint_as_float(raw[j].w));
         } else {
             const unsigned w[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
             float f[8];

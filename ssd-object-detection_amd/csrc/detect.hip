@@ -129,6 +129,7 @@ __device__ __forceinline__ float iou_f32(float4 a, float4 b) {
 }
 
 // exclusive prefix of a 0/1 flag over the workgroup (index order), and the total
+template <int NW>
 __device__ __forceinline__ int wg_prefix(bool flag, int* s_wave, int& total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long m = __ballot(flag);
@@ -138,11 +139,16 @@ __device__ __forceinline__ int wg_prefix(bool flag, int* s_wave, int& total) {
     __syncthreads();
     int base = 0;
     for (int w = 0; w < wave; ++w) base += s_wave[w];
-    total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) total += s_wave[w];
     return base + before;
 }
 
-__global__ __launch_bounds__(WG) void k_nms(const float* __restrict__ score, const int* __restrict__ cls,
+// One workgroup of 16 waves per image: the greedy pass runs one wave per class segment, ~80 short segments per image, and with
+// four waves it was 21 of the kernel's 39 us (stage times from a -DSSD_DEV_ABLATE build, tools_dev/time_detect.py).
+constexpr int NMS_WG = 1024;
+__global__ __launch_bounds__(NMS_WG) void k_nms(const float* __restrict__ score, const int* __restrict__ cls,
                                             const float4* __restrict__ box, const uint8_t* __restrict__ cand, int A,
                                             float iou_thresh, int max_cand, uint8_t* __restrict__ keep,
                                             int* __restrict__ keep_count, int ablate) {
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(WG) void k_nms(const float* __restrict__ score, con
     __shared__ unsigned char s_alive[CAP];
     __shared__ int s_seg[CAP + 1];
     __shared__ int s_hist[256];
-    __shared__ int s_wave[4];
+    __shared__ int s_wave[NMS_WG / 64];
     __shared__ int s_misc[4];
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -164,30 +170,48 @@ __global__ __launch_bounds__(WG) void k_nms(const float* __restrict__ score, con
     // key), so their order in s_key is irrelevant: one LDS counter, no barrier between the anchor strides, every load of
     // the sweep in flight at once.  (The ordered compaction further down -- needed only for the exact top-max_cand cut --
     // costs two workgroup prefix sums and a global-memory round trip per stride of 256 anchors, 34 strides per image.)
+    // Two memory round trips for the whole sweep: (1) every thread's candidate flags, all requests in flight together (the
+    // per-stride form -- load a flag word, branch, load class and score of its candidates, next stride -- ran ~17 dependent
+    // round trips: most of this kernel's time); the candidates' anchor indices go to an LDS list; (2) further down every thread
+    // fetches class, score AND box of "its" list entries at once (the boxes used to be a third trip behind the sort).
     if (tid < 4) s_misc[tid] = 0;
     __syncthreads();
-    auto take_cand = [&](int a) {
+    int* s_idx = s_seg;                      // [CAP] candidate anchors, unordered (s_seg is not in use yet)
+    auto note_cand = [&](int a) {
         const int slot = atomicAdd(&s_misc[0], 1);
-        if (slot < CAP)
-            s_key[slot] = ((unsigned long long)(unsigned)cls[off + a] << 48) |
-                          ((unsigned long long)(0xffffffffu - __float_as_uint(sc[a])) << 16) | (unsigned long long)(unsigned)a;
+        if (slot < CAP) s_idx[slot] = a;
     };
     if ((A & 3) == 0) {                      // rows of cand / keep are 4-byte aligned: four anchors per load / store
         const unsigned* cd4 = reinterpret_cast<const unsigned*>(cd);
         unsigned* kp4 = reinterpret_cast<unsigned*>(keep + off);
-        for (int q = tid; q < (A >> 2); q += WG) {
-            kp4[q] = 0u;
-            const unsigned c4 = cd4[q];
-            if (c4) {
+        const int nq = A >> 2;
+        constexpr int UN = 3;                // 3 x 1024 x 4 = 12288 >= 8732 anchors in one pass
+        for (int q0 = 0; q0 < nq; q0 += UN * NMS_WG) {
+            unsigned c4v[UN];
+#pragma unroll
+            for (int j = 0; j < UN; ++j) {
+                const int q = q0 + j * NMS_WG + tid;
+                const unsigned v = cd4[q < nq ? q : nq - 1];
+                c4v[j] = q < nq ? v : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < UN; ++j) {
+                const int q = q0 + j * NMS_WG + tid;
+                if (q < nq) kp4[q] = 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < UN; ++j) {
+                if (!c4v[j]) continue;
+                const int q = q0 + j * NMS_WG + tid;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if ((c4 >> (8 * e)) & 0xffu) take_cand(4 * q + e);
+                    if ((c4v[j] >> (8 * e)) & 0xffu) note_cand(4 * q + e);
             }
         }
     } else {
-        for (int a = tid; a < A; a += WG) {
+        for (int a = tid; a < A; a += NMS_WG) {
             keep[off + a] = 0;
-            if (cd[a]) take_cand(a);
+            if (cd[a]) note_cand(a);
         }
     }
     __syncthreads();
@@ -205,9 +229,9 @@ __global__ __launch_bounds__(WG) void k_nms(const float* __restrict__ score, con
         unsigned prefix = 0;
         int k = max_cand;                    // rank (1-based, from the top) still to locate
         for (int shift = 24; shift >= 0; shift -= 8) {
-            s_hist[tid] = 0;
+            if (tid < 256) s_hist[tid] = 0;
             __syncthreads();
-            for (int a = tid; a < A; a += WG)
+            for (int a = tid; a < A; a += NMS_WG)
                 if (cd[a]) {
                     const unsigned key = __float_as_uint(sc[a]);
                     if (shift == 24 || (key >> (shift + 8)) == prefix) atomicAdd(&s_hist[(key >> shift) & 255u], 1);
@@ -231,10 +255,39 @@ __global__ __launch_bounds__(WG) void k_nms(const float* __restrict__ score, con
         need_eq = k;                         // how many of the keys equal to the cut are still wanted
     }
 
+    // keys (+ boxes) of the listed candidates: one round trip, every load of a thread in flight together
+    constexpr int PER = CAP / NMS_WG;
+    float4 mybox[PER];
+    {
+        // (unconditional loads at clamped indices: a conditionally filled register array would live in scratch memory)
+        int an[PER];
+        unsigned cl[PER], sb[PER];
+        const int listed = min(total, CAP);
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int i = tid + e * NMS_WG;
+            const int a = s_idx[i < listed ? i : 0];
+            an[e] = min(max(a, 0), A - 1);
+        }
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            cl[e] = (unsigned)cls[off + an[e]];
+            sb[e] = __float_as_uint(sc[an[e]]);
+            mybox[e] = box[off + an[e]];
+        }
+        __syncthreads();                     // s_idx (= s_seg) is dead from here on
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int i = tid + e * NMS_WG;
+            if (total <= max_cand && i < total)
+                s_key[i] = ((unsigned long long)cl[e] << 48) | ((unsigned long long)(0xffffffffu - sb[e]) << 16) |
+                           (unsigned long long)(unsigned)an[e];
+        }
+    }
     if (total > max_cand) {
     // ordered compaction (anchor order) of the participating candidates
     int filled = 0, eq_seen = 0;
-    for (int a0 = 0; a0 < A; a0 += WG) {
+    for (int a0 = 0; a0 < A; a0 += NMS_WG) {
         const int a = a0 + tid;
         bool is_c = a < A && cd[a];
         unsigned key = is_c ? __float_as_uint(sc[a]) : 0u;
@@ -244,11 +297,11 @@ __global__ __launch_bounds__(WG) void k_nms(const float* __restrict__ score, con
             is_c = key > cut_bits || is_eq;
         }
         int tot_eq = 0;
-        const int eq_rank = wg_prefix(is_eq, s_wave, tot_eq);
+        const int eq_rank = wg_prefix<NMS_WG / 64>(is_eq, s_wave, tot_eq);
         if (is_eq && eq_seen + eq_rank >= need_eq) is_c = false;
         eq_seen += tot_eq;
         int tot = 0;
-        const int pos = wg_prefix(is_c, s_wave, tot);
+        const int pos = wg_prefix<NMS_WG / 64>(is_c, s_wave, tot);
         if (is_c) {
             const int slot = filled + pos;
             s_key[slot] = ((unsigned long long)(unsigned)cls[off + a] << 48) |
@@ -258,57 +311,36 @@ __global__ __launch_bounds__(WG) void k_nms(const float* __restrict__ score, con
     }
     }
     if (ablate & 1) return;
-    // sort ascending: class asc, score desc, anchor asc.  Up to 512 keys by rank (keys are unique: every thread counts the keys
-    // below its own with broadcast LDS reads and writes its key to that slot -- two barriers instead of the 45 of a 512-key
-    // bitonic network); more keys: bitonic, padded to a power of two
-    if (take <= 512) {
+    // sort ascending: class asc, score desc, anchor asc -- by rank (keys are unique: every thread counts the keys below its own
+    // with broadcast LDS reads and writes its key to that slot: two barriers instead of the 45+ of a bitonic network)
+    static_assert(CAP <= NMS_WG, "one key per thread");
+    {
         __syncthreads();
-        unsigned long long mine[2];
-        int rank[2] = {0, 0};
-#pragma unroll
-        for (int e = 0; e < 2; ++e) mine[e] = tid + e * WG < take ? s_key[tid + e * WG] : ~0ull;
-        for (int j = 0; j < take; ++j) {
-            const unsigned long long kj = s_key[j];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) rank[e] += kj < mine[e] ? 1 : 0;
+        const unsigned long long mine = tid < take ? s_key[tid] : ~0ull;
+        int rank = 0;
+        for (int j = 0; j < take; ++j) rank += s_key[j] < mine ? 1 : 0;
+        __syncthreads();
+        if (tid < take) {
+            s_key[rank] = mine;
+            // the box travels with its key: no gather behind the sort (component-wise: see stage_store)
+            if (total <= max_cand) s_box[rank] = make_float4(mybox[0].x, mybox[0].y, mybox[0].z, mybox[0].w);
         }
         __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-            if (tid + e * WG < take) s_key[rank[e]] = mine[e];
-        __syncthreads();
-    } else {
-    int npow = 1;
-    while (npow < take) npow <<= 1;
-    for (int i = take + tid; i < npow; i += WG) s_key[i] = ~0ull;
-    __syncthreads();
-    for (int k = 2; k <= npow; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < npow; i += WG) {
-                const int p = i ^ j;
-                if (p > i) {
-                    const unsigned long long x = s_key[i], y = s_key[p];
-                    const bool up = (i & k) == 0;
-                    if ((x > y) == up) { s_key[i] = y; s_key[p] = x; }
-                }
-            }
-            __syncthreads();
-        }
     }
     if (ablate & 2) return;
-    // gather boxes, mark class-segment starts
-    for (int i = tid; i < take; i += WG) {
-        const int a = (int)(s_key[i] & 0xffffull);
-        s_box[i] = box[off + a];
+    // gather boxes (unless they came with the keys), mark class-segment starts
+    const bool boxes_placed = total <= max_cand;
+    for (int i = tid; i < take; i += NMS_WG) {
+        if (!boxes_placed) s_box[i] = box[off + (int)(s_key[i] & 0xffffull)];
         s_alive[i] = 1;
     }
     if (tid == 0) s_misc[3] = 0;
     __syncthreads();
-    for (int i0 = 0; i0 < take; i0 += WG) {
+    for (int i0 = 0; i0 < take; i0 += NMS_WG) {
         const int i = i0 + tid;
         const bool start = i < take && (i == 0 || (s_key[i] >> 48) != (s_key[i - 1] >> 48));
         int tot = 0;
-        const int pos = wg_prefix(start, s_wave, tot);
+        const int pos = wg_prefix<NMS_WG / 64>(start, s_wave, tot);
         if (start) s_seg[s_misc[3] + pos] = i;
         __syncthreads();
         if (tid == 0) s_misc[3] += tot;
@@ -322,7 +354,7 @@ __global__ __launch_bounds__(WG) void k_nms(const float* __restrict__ score, con
     // greedy pass: one wave per class segment
     volatile unsigned char* alive = s_alive;
     int kept = 0;
-    for (int sg = wave; sg < nseg; sg += 4) {
+    for (int sg = wave; sg < nseg; sg += NMS_WG / 64) {
         const int lo = s_seg[sg], hi = s_seg[sg + 1];
         if (hi - lo <= 64) {
             // a segment that fits a wave (nearly all do) runs in registers: lane l holds box lo + l, the alive set is a
@@ -403,7 +435,7 @@ int ssd_nms(const float* score, const int32_t* cls, const float* box, const uint
             float iou_thresh, int max_cand, uint8_t* keep, int32_t* keep_count, void* stream) {
     if (B <= 0 || A <= 0 || A > 65536 || max_cand <= 0 || max_cand > CAP) return SSD_ERR_VALUE;
     if (!score || !cls || !box || !cand || !keep) return SSD_ERR_VALUE;
-    hipLaunchKernelGGL(k_nms, dim3(B), dim3(WG), 0, (hipStream_t)stream, score, cls, reinterpret_cast<const float4*>(box),
+    hipLaunchKernelGGL(k_nms, dim3(B), dim3(NMS_WG), 0, (hipStream_t)stream, score, cls, reinterpret_cast<const float4*>(box),
                        cand, A, iou_thresh, max_cand, keep, keep_count, nms_ablate());
     return ssd_launch_status();
 }

@@ -3,6 +3,9 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
+from ssd_object_detection_amd import _lib
+if os.environ.get('AB_LIB'):
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ['AB_LIB'])      # dev: a -DSSD_DEV_ABLATE build for the stage times
 import ssd_object_detection_amd.ops as ops
 B = 64
 pset = ops.build_priors()
@@ -13,7 +16,6 @@ for dt in (torch.float32, torch.bfloat16):
     t_nms = bench.graph_timed(torch, lambda: ops.nms(sd[0], sd[1], sd[2], sd[3], 0.45, 400), 30)
     print(dt, "score_decode %.1f us  (%.2f us/img, %.0f GB/s)  nms %.1f us" % (t_sd * 1e6, t_sd / B * 1e6,
           conf.numel() * conf.element_size() / t_sd / 1e9, t_nms * 1e6), flush=True)
-    from ssd_object_detection_amd import _lib
     L = _lib.lib()
     for a in (1, 2, 4):
         L.ssd_dev_knob(b"SSD_ABLATE", a)

@@ -1057,20 +1057,24 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
         // data gradient: the ReLU mask (the forward activation at the output position) is fetched NOW, ahead of the next
         // patch, and is in registers long before the epilogue needs it -- fetched there, every block paid a full memory
         // round trip with the matrix cores idle (300 us of the 630 us this kernel took)
-        uint4 mk[4];
-        int mk_m[4];
-        const bool premask = EPI == EPI_DGRAD && (ep.mask_src != nullptr || ep.mask_bits != nullptr) && !(g.ablate & 128);
+        // (only the sign-bit form of the mask is pre-fetched -- one register per chunk; a bf16 mask_src takes the shared staged
+        //  epilogue, which reads it there: holding four 16-byte masks across the MFMA phase cost 12 more registers in a kernel
+        //  that sits at the 256-register limit and spilled 20, each reload in the epilogue draining the store queue)
+        //  The four chunks of a thread sit in ONE column of the block, two rows apart: their pixel indices are recomputed where
+        //  they are used instead of being held across the MFMA phase.)
+        unsigned mk[4];
+        // chunk i of thread `t`: block row 2 i + (t >> 7), column (t >> 3) & 15, channels 8 (t & 7) .. +7; -1 = outside the map
+        auto chunk_pixel = [&](int t, int i) {
+            const int y = y0 + 2 * i + (t >> 7), xx = x0 + ((t >> 3) & 15);
+            return (y < g.Ho && xx < g.Wo) ? (b * g.Ho + y) * g.Wo + xx : -1;
+        };
+        const bool premask = EPI == EPI_DGRAD && ep.mask_bits != nullptr && !(g.ablate & 128);
         if constexpr (EPI == EPI_DGRAD) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int idx = i * 256 + tid, row = idx >> 3, ch = idx & 7;
-                const int y = y0 + (row >> 4), xx = x0 + (row & 15);
-                mk_m[i] = (y < g.Ho && xx < g.Wo) ? (b * g.Ho + y) * g.Wo + xx : -1;
-                mk[i] = make_uint4(0, 0, 0, 0);
-                if (premask && mk_m[i] >= 0) {
-                    if (ep.mask_bits) mk[i].x = ep.mask_bits[(long long)mk_m[i] * 8 + ch];       // sign bits: one byte instead of 16
-                    else mk[i] = *reinterpret_cast<const uint4*>(ep.mask_src + (long long)mk_m[i] * ep.ldo + ch * 8);
-                }
+                const int m = chunk_pixel(tid, i);
+                mk[i] = 0u;
+                if (premask && m >= 0) mk[i] = ep.mask_bits[(long long)m * 8 + (tid & 7)];
             }
         }
         const int tnext = block_of(it + 1);
@@ -1135,19 +1139,16 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
                     }
                 }
                 __syncthreads();
-                auto gate = [](unsigned val, unsigned m2) {
-                    if (!(__uint_as_float(m2 << 16) > 0.f)) val &= 0xffff0000u;
-                    if (!(__uint_as_float(m2 & 0xffff0000u) > 0.f)) val &= 0x0000ffffu;
-                    return val;
-                };
+                int t2 = tid;
+                asm volatile("" : "+v"(t2));                 // (opaque copy: keeps the compiler from carrying the indices over from above)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int idx = i * 256 + tid, row = idx >> 3, ch = idx & 7;
-                    if (mk_m[i] < 0) continue;
+                    const int idx = i * 256 + t2, row = idx >> 3, ch = idx & 7;
+                    const int m = chunk_pixel(t2, i);
+                    if (m < 0) continue;
                     uint4 v = *reinterpret_cast<const uint4*>(st + row * 128 + (((ch ^ row) & 7) << 4));
-                    if (ep.mask_bits) v = gate_bits8(v, mk[i].x);
-                    else { v.x = gate(v.x, mk[i].x); v.y = gate(v.y, mk[i].y); v.z = gate(v.z, mk[i].z); v.w = gate(v.w, mk[i].w); }
-                    *reinterpret_cast<uint4*>(ep.out + (long long)mk_m[i] * ep.ldo + ch * 8) = v;
+                    v = gate_bits8(v, mk[i]);
+                    *reinterpret_cast<uint4*>(ep.out + (long long)m * ep.ldo + ch * 8) = v;
                 }
             }
         } else {

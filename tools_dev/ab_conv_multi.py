@@ -34,6 +34,13 @@ for spec in sys.argv[1:]:
         dw, db = ops.conv2d_bwd_weight(x, dy, Cout, k, S, pt, pt)
         run = lambda: ops.conv2d_bwd_weight(x, dy, Cout, k, S, pt, pt, dw=dw, dbias=db)
         plan = lambda: L.ssd_conv2d_bwd_weight_plan(B, H, H, Cin, Cout, cp, k, S, pt, pt, Ho, Ho)
+    elif mode == "dgradbits":                       # the data gradient as the engine calls it: ReLU mask as sign bits
+        dy = torch.zeros((B, Ho, Ho, cp), device="cuda").bfloat16(); dy[..., :Cout] = torch.randn((B, Ho, Ho, Cout), device="cuda").bfloat16()
+        w_t = (torch.randn((Cin, k, k, cp), device="cuda") * 0.05).bfloat16()
+        dx = torch.empty((B, H, H, Cin), device="cuda", dtype=torch.bfloat16)
+        bits = torch.randint(0, 256, (B, H, H, Cin // 8), device="cuda", dtype=torch.uint8)
+        run = lambda: ops.conv2d_bwd_data_bits(dy, w_t, bits, (B, H, H, Cin), S, pt, pt, accumulate=False, out=dx)
+        plan = lambda: L.ssd_conv2d_bwd_data_plan(B, H, H, Cin, cp, k, S, pt, pt, Ho, Ho, 0, 1 << 25)
     else:
         dy = torch.zeros((B, Ho, Ho, cp), device="cuda").bfloat16(); dy[..., :Cout] = torch.randn((B, Ho, Ho, Cout), device="cuda").bfloat16()
         w_t = (torch.randn((Cin, k, k, cp), device="cuda") * 0.05).bfloat16()

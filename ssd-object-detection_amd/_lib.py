@@ -3,7 +3,8 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libssd_hip.so")
+# (SSD_HIP_LIB: development only -- another build of the library next to the default one, for same-box A/B runs)
+LIB_PATH = os.path.join(HERE, os.environ.get("SSD_HIP_LIB", "libssd_hip.so"))
 
 SSD_OK, SSD_ERR_ASSERT, SSD_ERR_VALUE, SSD_ERR_WORKSPACE, SSD_ERR_LAUNCH, SSD_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 SSD_MAX_LEVELS = 8

@@ -1152,7 +1152,8 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
                 }
             }
         } else {
-            staged_epilogue<EPI, 128, 64, 2, 4, 256>(acc, smem + C64B_STAGE, g, ep, 0, wave_m * 64, wave_n * 32, tid, row_to_m, pool_index);
+            staged_epilogue<EPI, 128, 64, 2, 4, 256, decltype(row_to_m), decltype(pool_index), false>(
+                acc, smem + C64B_STAGE, g, ep, 0, wave_m * 64, wave_n * 32, tid, row_to_m, pool_index);
         }
         // store instructions of that epilogue with at least one active lane (its loop: iteration i, wave w covers the
         // 8 pixels x = 8 (w & 1) .. +7 of block row 2 i + (w >> 1)): a lower bound of what this wave issued after the DMA

@@ -261,7 +261,7 @@ struct NoPool { __device__ long long operator()(int, int) const { return -1; } }
 // Second half of the staged epilogue: the [BM px][BN ch] bf16 tile image in LDS (layout above; FWD: bias and ReLU already
 // applied) leaves as whole 16-byte chunks of contiguous rows; DGRAD applies accumulate / ReLU mask here, FWD the fused pooling.
 // Caller: a barrier between the last write of the image and this call.
-template <int EPI, int BM, int BN, int NT, typename RowMap, typename PoolMap>
+template <int EPI, int BM, int BN, int NT, typename RowMap, typename PoolMap, bool DG_BATCHED = true>
 __device__ __forceinline__ void staged_store(char* smem, const ConvGeom& g, const Epilogue& ep, int n0, int tid, RowMap row_to_m,
                                              PoolMap pool_index) {
     constexpr int CPR = BN / 8;                 // 16-byte chunks per tile row
@@ -307,6 +307,96 @@ __device__ __forceinline__ void staged_store(char* smem, const ConvGeom& g, cons
         constexpr int ITER = BM * CPR / NT;
         // forward with fused pooling and no consumer of the full-resolution map (out == nullptr): only the pooled map leaves
         const bool store_full = EPI != EPI_FWD || ep.out != nullptr;
+        if constexpr (EPI == EPI_DGRAD && DG_BATCHED) {
+            // Data gradient: a chunk needs up to three global reads before it can be stored (the value to accumulate onto, the
+            // ReLU mask, the pooling codes).  Chunk by chunk -- load, wait, store, next -- every iteration was a full memory
+            // round trip that also waited for the previous chunk's store (s_waitcnt vmcnt counts stores too): 16 serialised
+            // round trips per 512-pixel tile with the matrix cores idle.  Here the reads of DG_BATCH chunks are issued
+            // together, unconditionally (a chunk outside the map reads element 0 and is dropped), then the chunks are
+            // finished: one round trip per batch.  (The registers are free: the accumulators went to LDS above.)
+            constexpr int DG_BATCH = ITER % 4 == 0 ? 4 : (ITER % 2 == 0 ? 2 : 1);
+            const long long nb8 = g.N >> 3;
+            for (int it0 = 0; it0 < ITER; it0 += DG_BATCH) {
+                int mm[DG_BATCH], rr[DG_BATCH], cc[DG_BATCH];
+                long long oo[DG_BATCH];
+                bool ok[DG_BATCH];
+#pragma unroll
+                for (int j = 0; j < DG_BATCH; ++j) {
+                    const int idx = (it0 + j) * NT + tid;
+                    rr[j] = idx / CPR; cc[j] = idx - rr[j] * CPR;
+                    const int n = n0 + cc[j] * 8;
+                    mm[j] = row_to_m(rr[j]);
+                    ok[j] = mm[j] >= 0 && n < g.N;
+                    oo[j] = ok[j] ? (long long)mm[j] * ep.ldo + n : 0;
+                }
+                uint4 old[DG_BATCH], mk[DG_BATCH];
+                unsigned mb[DG_BATCH], cw[DG_BATCH];
+#pragma unroll
+                for (int j = 0; j < DG_BATCH; ++j) { old[j] = mk[j] = make_uint4(0, 0, 0, 0); mb[j] = 0xffu; cw[j] = 0u; }
+                if (ep.accumulate) {
+#pragma unroll
+                    for (int j = 0; j < DG_BATCH; ++j) old[j] = *reinterpret_cast<const uint4*>(ep.out + oo[j]);
+                }
+                if (ep.mask_src) {
+#pragma unroll
+                    for (int j = 0; j < DG_BATCH; ++j) mk[j] = *reinterpret_cast<const uint4*>(ep.mask_src + oo[j]);
+                } else if (ep.mask_bits) {
+#pragma unroll
+                    for (int j = 0; j < DG_BATCH; ++j) mb[j] = ep.mask_bits[ok[j] ? (long long)mm[j] * nb8 + ((n0 >> 3) + cc[j]) : 0];
+                }
+                if (ep.up_code) {
+#pragma unroll
+                    for (int j = 0; j < DG_BATCH; ++j) cw[j] = ep.up_code[ok[j] ? (long long)mm[j] * nb8 + ((n0 >> 3) + cc[j]) : 0];
+                }
+#pragma unroll
+                for (int j = 0; j < DG_BATCH; ++j) {
+                    if (!ok[j]) continue;
+                    const int row = rr[j], ch = cc[j], m = mm[j];
+                    const int n = n0 + ch * 8;
+                    uint4 v = *reinterpret_cast<const uint4*>(smem + row * (BN * 2) + (((ch ^ row) & (CPR - 1)) << 4));
+                    if (ep.accumulate) {                          // out += result (two gradients meet at a feature map)
+                        auto add2 = [](unsigned a, unsigned b) {
+                            const float lo = __uint_as_float(a << 16) + __uint_as_float(b << 16);
+                            const float hi = __uint_as_float(a & 0xffff0000u) + __uint_as_float(b & 0xffff0000u);
+                            return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+                        };
+                        v.x = add2(v.x, old[j].x); v.y = add2(v.y, old[j].y); v.z = add2(v.z, old[j].z); v.w = add2(v.w, old[j].w);
+                    }
+                    if (ep.mask_src) {                            // ReLU backward: zero where the forward activation was <= 0
+                        auto gate = [](unsigned val, unsigned m2) {
+                            if (!(__uint_as_float(m2 << 16) > 0.f)) val &= 0xffff0000u;
+                            if (!(__uint_as_float(m2 & 0xffff0000u) > 0.f)) val &= 0x0000ffffu;
+                            return val;
+                        };
+                        v.x = gate(v.x, mk[j].x); v.y = gate(v.y, mk[j].y); v.z = gate(v.z, mk[j].z); v.w = gate(v.w, mk[j].w);
+                    } else if (ep.mask_bits) {
+                        v = gate_bits8(v, mb[j]);
+                    }
+                    if (ep.up_code) {                             // un-pool: the four positions of the window, winner or zero
+                        const int b = fdiv(m, g.d_hw);
+                        const int rem = m - b * g.d_hw.d;
+                        const int oy = fdiv(rem, g.d_w), ox = rem - oy * g.d_w.d;
+                        const unsigned gw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int iy = 2 * oy + (q >> 1), ix = 2 * ox + (q & 1);
+                            if (iy >= ep.up_h || ix >= ep.up_w) continue;
+                            unsigned w4[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const unsigned lo = ((cw[j] >> (8 * k)) & 15u) == (unsigned)q ? 0x0000ffffu : 0u;
+                                const unsigned hi = ((cw[j] >> (8 * k + 4)) & 15u) == (unsigned)q ? 0xffff0000u : 0u;
+                                w4[k] = gw[k] & (lo | hi);
+                            }
+                            *reinterpret_cast<uint4*>(ep.up_out + (((long long)b * ep.up_h + iy) * ep.up_w + ix) * g.N + n) =
+                                make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                        }
+                        if (!ep.out) continue;
+                    }
+                    *reinterpret_cast<uint4*>(ep.out + oo[j]) = v;
+                }
+            }
+        } else
 #pragma unroll 4
         for (int it = 0; it < (store_full ? ITER : 0); ++it) {
             const int idx = it * NT + tid;
@@ -442,7 +532,9 @@ __device__ __forceinline__ void staged_store(char* smem, const ConvGeom& g, cons
     }
 }
 
-template <int EPI, int BM, int BN, int CT, int PT, int NT, typename RowMap, typename PoolMap>
+// DG_BATCHED = false: the data gradient's chunk-by-chunk store loop (fewer registers: for a kernel at its register limit whose
+// data gradient normally leaves through its own path, k_conv3x3_c64b)
+template <int EPI, int BM, int BN, int CT, int PT, int NT, typename RowMap, typename PoolMap, bool DG_BATCHED = true>
 __device__ __forceinline__ void staged_epilogue(f32x4_t (&acc)[CT][PT], char* smem, const ConvGeom& g, const Epilogue& ep,
                                                 int n0, int wrow0, int wcol0, int tid, RowMap row_to_m, PoolMap pool_index) {
     constexpr int CPR = BN / 8;                 // 16-byte chunks per tile row
@@ -469,7 +561,7 @@ __device__ __forceinline__ void staged_epilogue(f32x4_t (&acc)[CT][PT], char* sm
         }
     }
     __syncthreads();
-    staged_store<EPI, BM, BN, NT>(smem, g, ep, n0, tid, row_to_m, pool_index);
+    staged_store<EPI, BM, BN, NT, RowMap, PoolMap, DG_BATCHED>(smem, g, ep, n0, tid, row_to_m, pool_index);
 }
 
 // callers without a pooling stage

@@ -616,12 +616,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         pvo[j] = (sl < 4 && pix >= 0) ? ((unsigned)pix * (unsigned)g.C + (unsigned)(sl * 8)) * 2u : OOB;
     }
     // weight DMA: instruction i = wave (< BN/16) fills rows 16i .. 16i+15; lane L -> row 16i + (L>>2), physical piece L & 3
+    // BN = 64: the slices of TWO taps are staged per step (image rows 0..63 = the first tap, 64..127 = the second: the same
+    // 128-row image and the same 80 KB of LDS as BN = 128), see the loop below
     unsigned wvo;
     {
         const int row = 16 * wave + (lane >> 2);
         const int piece = (lane & 3) ^ ((-(row >> 2)) & 3);
-        const int n = n0 + row;
-        wvo = (row < BN && n < g.N) ? ((unsigned)n * (unsigned)g.ldw + (unsigned)(piece * 8)) * 2u : OOB;
+        const int n = n0 + (BN == 64 ? (row & 63) : row);
+        wvo = (row < (BN == 64 ? 128 : BN) && n < g.N) ? ((unsigned)n * (unsigned)g.ldw + (unsigned)(piece * 8)) * 2u : OOB;
     }
     const int wdst = wave < BN / 16 ? wave * 1024 : -1;     // -1: dummy
     const int nchunk = g.C >> 5;
@@ -664,6 +666,58 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     auto ldf = [&](int addr) { return *reinterpret_cast<const bf16x8_t*>(smem + addr); };
 
+    if constexpr (BN == 64) {
+        // 64 output channels: a wave has 8 MFMAs per tap, and with one barrier per tap the loop ran at 0.24 of the MFMA peak
+        // (block2_conv1's data gradient).  Two taps per step: 16 MFMAs between barriers, five steps per chunk instead of
+        // nine.  Waves 0-3 request the first tap's slice of a step, waves 4-7 the second's (out of range for the missing
+        // tenth tap: zeros, never read), so every wave issues exactly one weight request per step and the counted waits of
+        // the single-tap form carry over.
+        constexpr int WB2 = 2 * WBYTES;
+        auto dma_w2 = [&](int chunk, int step, int buf) {
+            const int tap = 2 * step + (wave >> 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_void*)(smem + OFF_W + buf * WB2 + wave * 1024), 16,
+                                                     tap <= 8 ? wvo : OOB, ((tap <= 8 ? tap : 8) * g.C + chunk * 32) * 2, 0, 0);
+        };
+        dma_patch(0, 0);
+        dma_w2(0, 0, 0);
+        for (int chunk = 0; chunk < nchunk; ++chunk) {
+            const int pb = (chunk & 1) * P32_PATCH;
+            const bool next_chunk = chunk + 1 < nchunk;
+#pragma unroll
+            for (int st = 0; st < 5; ++st) {
+                const int sidx = chunk * 5 + st;
+                const int wb = (sidx & 1) * WB2;
+                if (st == 1 && next_chunk) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (!(g.ablate & 16)) {
+                    if (st < 4) dma_w2(chunk, st + 1, (sidx + 1) & 1);
+                    else if (next_chunk) dma_w2(chunk + 1, 0, (sidx + 1) & 1);
+                }
+                if (st == 0 && next_chunk && !(g.ablate & 32)) dma_patch(chunk + 1, (chunk + 1) & 1);
+                bf16x8_t fx[2][PT], fw[2][CT];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int tap = 2 * st + t;
+                    if (tap > 8) continue;
+                    const int tapoff = pb + xbase + ((tap / 3) * Q + tap % 3) * P32_PITCH;
+#pragma unroll
+                    for (int p = 0; p < PT; ++p) fx[t][p] = ldf(tapoff + p * prow);
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) fw[t][c] = ldf(wb + wbase + t * WBYTES + c * 1024);
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    if (2 * st + t > 8) continue;
+#pragma unroll
+                    for (int c = 0; c < CT; ++c)
+#pragma unroll
+                        for (int p = 0; p < PT; ++p)
+                            acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[t][c], fx[t][p], acc[c][p], 0, 0, 0);
+                }
+            }
+        }
+    } else {
     dma_patch(0, 0);
     dma_w(0, 0, 0);
     for (int chunk = 0; chunk < nchunk; ++chunk) {
@@ -696,6 +750,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 for (int p = 0; p < PT; ++p)
                     acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[c], fx[p], acc[c][p], 0, 0, 0);
         }
+    }
     }
     if (staged_ok<EPI>(g, ep) && !(g.ablate & 8)) {          // tile image [256 block pixels][BN] in the (now idle) patch buffers
         auto row_to_m = [&](int row) {
@@ -2426,7 +2481,7 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
                                       : (rowflat ? strip_rows * (unsigned)tiles_x : gx);
 #define SSD_LAUNCH_P32(BN_, FLAT_)                                                                                  \
             do {                                                                                                    \
-                constexpr int lds_ = 2 * P32_PATCH + 2 * BN_ * 64 + (BN_ == 64 ? 1024 : 0);                         \
+                constexpr int lds_ = 2 * P32_PATCH + 2 * (BN_ == 64 ? 128 : BN_) * 64;   /* BN = 64 stages two taps per step */ \
                 auto kern_ = k_conv3x3_patch32<BN_, EPI, FLAT_>;                                                    \
                 SSD_PLAN((BN_ == 64 ? SSD_PLAN_P32_64 : SSD_PLAN_P32_128) | (FLAT_ ? SSD_PLAN_F_FLAT : 0) |            \
                          (rowflat ? SSD_PLAN_F_ROWFLAT : 0) | (can_pool ? SSD_PLAN_F_POOL_FUSED : 0));                \

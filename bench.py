@@ -189,13 +189,14 @@ def run_rank(args):
         batches.append((img, ops.pack_gt(box_l, cls_l)))
     pset = model._pset
     match_out = None
+    xbuf = torch.empty((B, 300, 300, 8), dtype=torch.bfloat16, device="cuda")      # the network input, one buffer for every step
 
     def step(i):
         nonlocal match_out
         img, gt = batches[i % NBATCH]
         match_out = model.match_async(gt, out=match_out)     # A3-A5 on the device, side stream, under the forward pass
         cls, loc, mask = match_out
-        x = ops.image_prep(img, normalize=True)              # A8: (x-0.5)*2, bf16, 8 channels -- one fused pass
+        x = ops.image_prep(img, normalize=True, out=xbuf)    # A8: (x-0.5)*2, bf16, 8 channels -- one fused pass
         model._train_step(x, cls, loc, mask, opt)
 
     def sync_all():

@@ -358,12 +358,14 @@ def _bf(t):
     return t
 
 
-def image_prep(img, normalize=True):
+def image_prep(img, normalize=True, out=None):
     """f32 [B,H,W,3] in [0,1] -> bf16 [B,H,W,8] with (x-0.5)*2 (models/ssd_model.py:214), zero-padded channels."""
     L = _lib.lib()
     _dev(img, torch.float32)
     B, H, W, _ = img.shape
-    out = torch.empty((B, H, W, 8), dtype=torch.bfloat16, device=img.device)
+    if out is None:
+        out = torch.empty((B, H, W, 8), dtype=torch.bfloat16, device=img.device)
+    assert out.shape == (B, H, W, 8) and out.dtype == torch.bfloat16 and out.is_contiguous()
     _lib.check(L.ssd_image_prep(_ptr(img), _ptr(out), B, H, W, 1 if normalize else 0, _stream()))
     return out
 

@@ -169,6 +169,10 @@ def run_rank(args):
 
     import ssd_object_detection_amd.ops as ops
     from ssd_object_detection_amd import optimizers
+    for kv in filter(None, os.environ.get("SSD_BENCH_KNOBS", "").split(",")):      # development: NAME=VALUE dispatch overrides
+        from ssd_object_detection_amd import _lib                                  # (same-box A/B of a kernel choice)
+        name, val = kv.split("=")
+        _lib.check(_lib.lib().ssd_dev_knob(name.encode(), int(val)))
     from ssd_object_detection_amd.models import SSDObjectDetectionModel
     from ssd_object_detection_amd.data_loaders.synthetic import synth_batch_gt
 
@@ -396,12 +400,16 @@ def kernel_sections(np, torch, ops, model, eng, pset, batches, match_out, B, res
         # algorithmic bytes are one read of conf + loc and the targets; the dense form is timed beside it
         t_loss = graph_timed(torch, lambda: ops.ssd_loss_heads(pconf, ploc, cls, loc, mask, hgb), 30)
         t_dense = graph_timed(torch, lambda: ops.ssd_loss(pconf, ploc, cls, loc, mask), 30)
-        lbytes = B * pset.A * (81 * s + 4 * s + 16 + 4 + 1)
+        # algorithmic bytes = SURVEY.md 8(d)'s figure for the loss (conf + loc read, dconf + dloc written, targets): 3.15 MB per
+        # image with bf16 logits -- kept for both forms so that they compare; the rows form does not perform the dense
+        # gradient write (bytes_moved_by_this_form)
+        lbytes = B * pset.A * (2 * 81 * s + 2 * 4 * s + 16 + 4 + 1)
         counts = hgb.count.cpu().tolist()[:hgb.levels]
-        result["roofline_loss"] = hbm_entry("ssd_loss_fwd_bwd_heads (k_loss_rows, k_loss_hist/select, k_hg_count/assign, k_loss_grad_rows, k_loss_final)",
+        moved = B * pset.A * (81 * s + 4 * s + 16 + 4 + 1) + sum(c * p * 2 for c, p in zip(counts, hgb.npad))
+        result["roofline_loss"] = hbm_entry("ssd_loss_fwd_bwd_heads (k_loss_rows, k_loss_hist, k_hg_count/assign, k_loss_grad_rows, k_loss_final)",
                                             lbytes, t_loss, B, logits="bf16", batch_us=round(t_loss * 1e6, 2),
-                                            dense_gradient_form_us=round(t_dense * 1e6, 2), gradient_rows_per_level=counts,
-                                            pixels_per_level=[B * h for h in hgb.hw])
+                                            dense_gradient_form_us=round(t_dense * 1e6, 2), bytes_moved_by_this_form=int(moved),
+                                            gradient_rows_per_level=counts, pixels_per_level=[B * h for h in hgb.hw])
     else:
         t_loss = graph_timed(torch, lambda: ops.ssd_loss(pconf, ploc, cls, loc, mask), 30)
         lbytes = B * pset.A * (2 * 81 * s + 2 * 4 * s + 16 + 4 + 1)      # conf+loc in, dconf+dloc out, gloc f32x4, cls i32, mask u8

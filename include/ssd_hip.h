@@ -244,6 +244,18 @@ int ssd_conv2d_fwd_relubits(const void* x, const void* w, const float* bias, voi
 int ssd_conv2d_bwd_data_bits(const void* dy, const void* w_t, const void* relu_bits, void* dx, int B, int H, int W, int Cin,
                              int Cout_pad, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, int accumulate, void* ws,
                              size_t ws_bytes, void* stream);
+/* Second layer's data gradient and first layer's weight gradient in ONE launch (block1_conv2 / block1_conv1 of the VGG-16
+ * trunk, models/ssd_model.py:62-66): the gradient w.r.t. the first layer's output has a single consumer, the 3-channel first
+ * layer's weight gradient, so it is multiplied with the image patch where it is produced and never stored -- equal to
+ *   ssd_conv2d_bwd_data_bits(dy, w_t, relu_bits, dx, B,H,W, 64, 64, 3,1,1,1, H,W, 0, ...)  followed by
+ *   ssd_conv2d_bwd_weight(image, dx, dw0, dbias0, B,H,W, 8, 64, 64, 3,1,1,1, H,W, ...)
+ * up to fp32 summation order (dx is rounded to bf16 in both).  dy [B,H,W,64] bf16; w_t [64][3][3][64] (ssd_weight_transpose
+ * of the second layer); relu_bits [B*H*W][8] (ssd_conv2d_fwd_relubits of the first layer); image [B,H,W,8] bf16
+ * (ssd_image_prep); dw0 f32 [64][3][3][8] (columns of the five pad channels: zeros); dbias0 f32 [64] or NULL.  Fixed summation
+ * order (one slab per workgroup in ws, reduced in order): bitwise reproducible.  H, W >= 16. */
+size_t ssd_conv2d_bwd_data_wgrad_first_workspace_bytes(int B, int H, int W);
+int ssd_conv2d_bwd_data_wgrad_first(const void* dy, const void* w_t, const void* relu_bits, const void* image, float* dw0,
+                                    float* dbias0, int B, int H, int W, void* ws, size_t ws_bytes, void* stream);
 /* The 3x3 / stride 1 / pad 1 data gradient w.r.t. a POOLED map [B,H,W,Cin], carried on through the 2x2 / stride-2 max
  * pooling that produced the map: dx_full[B,Hf,Wf,Cin] = ssd_maxpool2x2_bwd_argmax(pool_code, ssd_conv2d_bwd_data(...)) in
  * one launch, bit-identical (the un-pooling runs in the convolution's store stage: no pooled gradient in HBM, no second

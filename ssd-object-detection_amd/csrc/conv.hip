@@ -1027,9 +1027,36 @@ constexpr int C64B_PATCH = C64B_NDMA * 1024;               // 29696 B per buffer
 constexpr int C64B_STAGE = 2 * C64B_PATCH;                 // [128 px][64 ch] bf16 staging tile (16 KB)
 constexpr int C64B_LDS = C64B_STAGE + 128 * 128;
 
-template <int EPI>
+// W0 form (block1_conv2's data gradient + block1_conv1's weight gradient in one kernel).  The gradient this layer produces has
+// exactly one consumer -- the weight gradient of the 3-channel first layer, dW0[co][tap][ci] = sum_px dX[px][co] * img[px +
+// tap][ci] -- and that consumer was a pure HBM stream (k_conv0_wgrad: 737 MB read, 187 us at batch 64) behind a 737 MB
+// write here.  The masked bf16 tile is already in LDS for the store stage: instead of storing it, the four waves multiply
+// it with the 10 x 18 image halo patch (channels 0..3 of the 16-byte pixel, fetched by 4-byte LDS-DMA next to the 64-channel
+// patch): wave w owns output channels 16 w .. +15, three column tiles of (4 taps x 4 channels) -- the pad channel of the
+// centre tap carries ones, i.e. the bias gradient --, four k-steps of 32 pixels: 12 MFMAs and 32 transposing LDS reads per
+// wave and block next to the 144 MFMAs of the convolution.  The running sums live in LDS (the kernel has no register to
+// spare), one [64][72] + [64] fp32 slab per workgroup leaves at the end; nothing else is written.
+struct C64W0 {
+    const bf16_raw* img;                                    // [B][H][W][8] bf16 (ssd_image_prep), channels 3..7 zero
+    float* slab_w;                                          // [gridDim.x][64][72]
+    float* slab_b;                                          // [gridDim.x][64]
+};
+constexpr int C64B_IMG = 6 * 256;                           // 180 halo pixels x 8 bytes = six 4-byte DMA instructions
+constexpr int C64B_W0_IMG = 2 * C64B_PATCH;                 // (the staging tile reuses the patch buffer just consumed)
+constexpr int C64B_W0_SUMS = C64B_W0_IMG + 2 * C64B_IMG;
+constexpr int C64B_W0_LDS = C64B_W0_SUMS + 4 * 3 * 64 * 16; // [wave][column tile][lane] f32x4
+
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
+__device__ __forceinline__ s16x4_t lds_read_tr16_scoped(const char* __restrict__ p, const char* __restrict__ other) {
+    (void)other;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+}
+
+template <int EPI, bool W0 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ w, ConvGeom g, Epilogue ep, int tiles_x, int tiles_y) {
+void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ w, ConvGeom g, Epilogue ep, int tiles_x, int tiles_y,
+                    C64W0 w0) {
+    static_assert(!W0 || EPI == EPI_DGRAD, "the fused first-layer weight gradient belongs to the data gradient");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1038,6 +1065,7 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
     const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (unsigned)g.B * g.H * g.W * 64u * 2u, 0x00020000);
     constexpr unsigned OOB = 0xfffffff0u;
     constexpr int NJ = (C64B_NDMA + 3) / 4;                 // DMA instructions per wave: i = wave + 4 j
+    const __amdgpu_buffer_rsrc_t ires = __builtin_amdgcn_make_buffer_rsrc((void*)(W0 ? w0.img : x), 0, (unsigned)g.B * g.H * g.W * 16u, 0x00020000);
 
     int pcode[NJ];                                          // py << 16 | px << 8 | byte offset of the piece, -1 = padding
 #pragma unroll
@@ -1060,6 +1088,20 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
                 const unsigned off = (unsigned)((b * g.H + iy) * g.W + ix) * 128u + (unsigned)(pcode[j] & 255);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)(smem + buf * C64B_PATCH + (wave + 4 * j) * 1024), 16,
                                                          ok ? off : OOB, 0, 0, 0);
+            }
+        }
+        if constexpr (W0) {                                 // image halo: dword q = pixel q / 2, channels 2 (q & 1) .. +1
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (wave + 4 * j < 6) {
+                    const int q = (wave + 4 * j) * 64 + lane, pp = q >> 1;
+                    const int py = pp / PATCH_W, px = pp - py * PATCH_W;
+                    const int iy = ty * C64B_ROWS - 1 + py, ix = tx * 16 - 1 + px;
+                    const bool ok = pp < C64B_PATCH_PIX && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+                    const unsigned off = (unsigned)((b * g.H + iy) * g.W + ix) * 16u + (unsigned)(q & 1) * 4u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ires, (lds_void*)(smem + C64B_W0_IMG + buf * C64B_IMG + (wave + 4 * j) * 256), 4,
+                                                             ok ? off : OOB, 0, 0, 0);
+                }
             }
         }
     };
@@ -1090,6 +1132,11 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
             }
     }
     const int xbase = (4 * wave_m * PATCH_W + frow) * C64_PITCH + fk * 16;
+    if constexpr (W0) {                                     // this wave's running sums (no other wave touches them)
+        f32x4_t* sums = reinterpret_cast<f32x4_t*>(smem + C64B_W0_SUMS) + wave * 3 * 64 + lane;
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) sums[nt * 64] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
 
     int it = 0, prev_st = 0;
     for (int t = block_of(0); t >= 0; t = block_of(++it)) {
@@ -1178,6 +1225,76 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
             const int gy = (y0 >> 1) + py, gx = (x0 >> 1) + px;
             return (gy < ep.pool_h && gx < ep.pool_w) ? ((long long)b * ep.pool_h + gy) * ep.pool_w + gx : -1;
         };
+        if constexpr (W0) {
+            // (the host only launches this form with sign bits: premask holds)
+            char* st = smem + cur * C64B_PATCH;             // staging tile [128 px][64 ch] over the patch every wave is done with
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int col = wave_n * 32 + c * 16 + (lane >> 4) * 4;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int row = wave_m * 64 + p * 16 + (lane & 15);
+                    *reinterpret_cast<uint2*>(st + row * 128 + ((((col >> 3) ^ row) & 7) << 4) + (col & 4) * 2) =
+                        make_uint2((unsigned)f2bf(acc[c][p][0]) | ((unsigned)f2bf(acc[c][p][1]) << 16),
+                                   (unsigned)f2bf(acc[c][p][2]) | ((unsigned)f2bf(acc[c][p][3]) << 16));
+                }
+            }
+            __syncthreads();
+            int t2 = tid;
+            asm volatile("" : "+v"(t2));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                   // ReLU mask in place (pixels outside the map: mk = 0, i.e. zeros)
+                const int idx = i * 256 + t2, row = idx >> 3, ch = idx & 7;
+                uint4* slot = reinterpret_cast<uint4*>(st + row * 128 + (((ch ^ row) & 7) << 4));
+                *slot = gate_bits8(*slot, mk[i]);
+            }
+            __syncthreads();
+            // dW0 tile of this wave: D[co = 16 wave + 4 (lane >> 4) + j][column = lane & 15] over the 128 pixels of the block.
+            // MFMA k index 8 g + e of k-step s  <->  block pixel 32 s + 8 g + e (row 2 s + (g >> 1), column 8 (g & 1) + e); both
+            // operands come through the transposing read: lane 4 q + p of a 16-lane group supplies the address of k row q (+ 4
+            // for the second half), elements 4 p .. 4 p + 3 of the 16 columns.
+            int l2 = t2 & 63;
+            const int gq = l2 >> 4, q = (l2 >> 2) & 3, p4 = l2 & 3;
+            int db[2], ib[3];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r = 8 * gq + q + 4 * h;
+                db[h] = r * 128 + ((((2 * wave + (p4 >> 1)) ^ r) & 7) << 4) + (p4 & 1) * 8;
+            }
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) {                // column 4 p + ci of tile nt = tap 4 nt + p, image channel ci
+                int tap = 4 * nt + p4;
+                if (tap > 8) tap = 8;                       // (columns of taps 9..11 are never stored)
+                ib[nt] = (((gq >> 1) + tap / 3) * PATCH_W + 8 * (gq & 1) + q + tap % 3) * 8;
+            }
+            const char* im = smem + C64B_W0_IMG + cur * C64B_IMG;
+            f32x4_t* sums = reinterpret_cast<f32x4_t*>(smem + C64B_W0_SUMS) + wave * 3 * 64 + l2;
+            f32x4_t aw[3];
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) aw[nt] = sums[nt * 64];
+            bf16x8_t ones;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                bf16x8_t fd;
+                reinterpret_cast<s16x4_t*>(&fd)[0] = lds_read_tr16_scoped(st + db[0] + s * 4096, smem);
+                reinterpret_cast<s16x4_t*>(&fd)[1] = lds_read_tr16_scoped(st + db[1] + s * 4096, smem);
+#pragma unroll
+                for (int nt = 0; nt < 3; ++nt) {
+                    bf16x8_t fp;
+                    reinterpret_cast<s16x4_t*>(&fp)[0] = lds_read_tr16_scoped(im + ib[nt] + s * (2 * PATCH_W * 8), smem);
+                    reinterpret_cast<s16x4_t*>(&fp)[1] = lds_read_tr16_scoped(im + ib[nt] + s * (2 * PATCH_W * 8) + 32, smem);
+                    if (nt == 1) fp = (l2 & 15) == 3 ? ones : fp;   // centre tap, pad channel: the bias gradient
+                    aw[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd, fp, aw[nt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) sums[nt * 64] = aw[nt];
+            prev_st = 0;                                    // nothing was stored: only the DMA is in flight
+            continue;
+        }
         if (premask) {
             if constexpr (EPI == EPI_DGRAD) {               // staged_epilogue's data-gradient path with the mask already here
                 char* st = smem + C64B_STAGE;
@@ -1218,6 +1335,23 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
         if (EPI == EPI_FWD && !ep.out) prev_st = 0;          // pool-only: no full-resolution stores
         // fused pooling: wave w stores pooled row (y0 >> 1) + w, columns (x0 >> 1) .. + 7 (pooled map, then the codes)
         if (EPI == EPI_FWD && ep.pool_out && (y0 >> 1) + wave < ep.pool_h && (x0 >> 1) < ep.pool_w) prev_st += 2;
+    }
+    if constexpr (W0) {                                     // this workgroup's slab, in the layout of k_conv0_wgrad's
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        const float* sm = reinterpret_cast<const float*>(smem + C64B_W0_SUMS);
+        auto tile_value = [&](int co, int tap, int ci) {    // D element (row co & 15, column 4 (tap & 3) + ci) of tile (co >> 4, tap >> 2)
+            const int l = 16 * ((co & 15) >> 2) + 4 * (tap & 3) + ci;
+            return sm[(((co >> 4) * 3 + (tap >> 2)) * 64 + l) * 4 + (co & 3)];
+        };
+        for (int idx = tid; idx < 64 * 72 + 64; idx += 256) {
+            if (idx < 64 * 72) {
+                const int co = idx / 72, col = idx - co * 72;
+                w0.slab_w[(long long)blockIdx.x * (64 * 72) + idx] = (col & 7) < 3 ? tile_value(co, col >> 3, col & 7) : 0.f;
+            } else if (w0.slab_b) {
+                w0.slab_b[(long long)blockIdx.x * 64 + (idx - 64 * 72)] = tile_value(idx - 64 * 72, 4, 3);
+            }
+        }
     }
 }
 
@@ -1504,11 +1638,7 @@ __global__ __launch_bounds__(WG) void k_conv_wgrad(const bf16_raw* __restrict__ 
 // orders an LDS read behind every in-flight LDS-DMA (s_waitcnt vmcnt(0)) unless the read has scope information; without it
 // the first fragment read of a step waited for the NEXT tile's DMA issued just before, i.e. the double buffer never
 // overlapped a transfer with the MFMAs.  The kernels order DMA and reads themselves (s_waitcnt vmcnt + barrier per step).
-typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
-__device__ __forceinline__ s16x4_t lds_read_tr16_scoped(const char* __restrict__ p, const char* __restrict__ other) {
-    (void)other;
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
-}
+// (lds_read_tr16_scoped: defined in front of k_conv3x3_c64b)
 
 constexpr int WT_TILE = 64 * 512;                          // one [64 px][256 ch] image
 __global__ __launch_bounds__(512) void k_conv_wgrad_tile(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ dy,
@@ -2450,10 +2580,10 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
             // 8 x 16 blocks, two workgroups per CU
             const int tiles_x = (g.Wo + 15) / 16, tiles_y = (g.Ho + C64B_ROWS - 1) / C64B_ROWS;
             const int nblocks = g.B * tiles_x * tiles_y;
-            auto kern = k_conv3x3_c64b<EPI>;
+            auto kern = k_conv3x3_c64b<EPI, false>;
             SSD_PLAN(SSD_PLAN_C64B | ((pooled && ep.pool_out) ? SSD_PLAN_F_POOL_FUSED : 0));
             static OnceLds set; if (ensure_lds(set, reinterpret_cast<const void*>(kern), (int)(C64B_LDS)) != 0) return SSD_ERR_LAUNCH;
-            hipLaunchKernelGGL(kern, dim3((unsigned)(nblocks < 512 ? nblocks : 512)), dim3(256), C64B_LDS, s, xp, wp, g, ep, tiles_x, tiles_y);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(nblocks < 512 ? nblocks : 512)), dim3(256), C64B_LDS, s, xp, wp, g, ep, tiles_x, tiles_y, C64W0{});
             if (pooled && ep.pool_out) *pooled = true;
             return ssd_launch_status();
         }
@@ -2784,6 +2914,40 @@ static void launch_wgrad_reduce(hipStream_t s, const float* slab_w, long long sw
         const unsigned nbw = (unsigned)((nw / 4 + 255) / 256), nbb = db ? (unsigned)((nb + 255) / 256) : 0u;
         hipLaunchKernelGGL(k_wgrad_reduce2, dim3(nbw + nbb), dim3(256), 0, s, slab_w, sw, nw, dw, slab_b, sb, nb, db, ns, nbw);
     }
+}
+
+// Data gradient of the second layer (64 -> 64, 3x3 / stride 1 / pad 1) fused with the weight gradient of the first
+// (8 padded image channels -> 64): k_conv3x3_c64b<EPI_DGRAD, true>.  The gradient w.r.t. the first layer's output never
+// reaches memory.  dy [B,H,W,64]; w_t [64][3][3][64] (ssd_weight_transpose of the second layer); relu_bits [B*H*W][8] (sign
+// bits of the first layer's output, ssd_conv2d_fwd_relubits); image [B,H,W,8]; dw0 f32 [64][3][3][8] (pad channels: zeros),
+// dbias0 f32 [64] or null.  One fp32 slab per workgroup, summed in a fixed order by the reduction kernel.
+size_t ssd_conv2d_bwd_data_wgrad_first_workspace_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)512 * (64 * 72 + 64) * sizeof(float);
+}
+
+int ssd_conv2d_bwd_data_wgrad_first(const void* dy, const void* w_t, const void* relu_bits, const void* image, float* dw0,
+                                    float* dbias0, int B, int H, int W, void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !w_t || !relu_bits || !image || !dw0 || B <= 0 || H <= 0 || W <= 0) return SSD_ERR_VALUE;
+    if (H < 16 || W < 16 || (long long)B * H * W * 64 >= (1ll << 31) - 16) return SSD_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < ssd_conv2d_bwd_data_wgrad_first_workspace_bytes(B, H, W)) return SSD_ERR_WORKSPACE;
+    const ConvGeom g = make_geom(B, H, W, 64, H, W, 64, 3, 3, 1, 1, 1, 1);
+    Epilogue ep = {};
+    ep.ldo = 64;
+    ep.mask_bits = static_cast<const unsigned char*>(relu_bits);
+    const int tiles_x = (W + 15) / 16, tiles_y = (H + C64B_ROWS - 1) / C64B_ROWS;
+    const int nblocks = B * tiles_x * tiles_y;
+    const unsigned grid = (unsigned)(nblocks < 512 ? nblocks : 512);
+    float* slab_w = static_cast<float*>(ws);
+    float* slab_b = slab_w + (size_t)512 * 64 * 72;
+    hipStream_t s = (hipStream_t)stream;
+    auto kern = k_conv3x3_c64b<EPI_DGRAD, true>;
+    static OnceLds set; if (ensure_lds(set, reinterpret_cast<const void*>(kern), (int)(C64B_W0_LDS)) != 0) return SSD_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C64B_W0_LDS, s, static_cast<const bf16_raw*>(dy), static_cast<const bf16_raw*>(w_t),
+                       g, ep, tiles_x, tiles_y, C64W0{static_cast<const bf16_raw*>(image), slab_w, dbias0 ? slab_b : nullptr});
+    if (hipGetLastError() != hipSuccess) return SSD_ERR_LAUNCH;
+    launch_wgrad_reduce(s, slab_w, 64ll * 72, 64ll * 72, dw0, slab_b, 64ll, 64, dbias0, (int)grid);
+    return ssd_launch_status();
 }
 
 // first layer (8 padded image channels): dedicated kernel, 512 pixel-block splits at most

@@ -121,6 +121,9 @@ class SSDEngine:
         # key (str) -> that kernel reads them
         self.relu_bits = {} if os.environ.get("SSD_RELU_BITS", "1") == "1" else None
         self.bits_valid = set()
+        # second layer's data gradient and first layer's weight gradient in one kernel (the gradient w.r.t. the first layer's
+        # output has no other consumer and is never stored); False after a refusal
+        self.fuse_first = os.environ.get("SSD_FUSE_FIRST", "1") == "1"
 
     # ---------------------------------------------------------------- static planning
     def _plan_shapes(self):
@@ -568,6 +571,7 @@ class SSDEngine:
         opt_bucket(None)
         # trunk, last layer first
         unpooled = set()                          # pooling nodes whose backward pass ran inside the next convolution's data gradient
+        first_fused = False
         for i in range(len(self.nodes) - 1, -1, -1):
             nd = self.nodes[i]
             g_out = gacts[i + 1]
@@ -579,12 +583,30 @@ class SSDEngine:
                 written[i] = True
                 continue
             wt, bt = self.conv_params[i]
+            if i == 0 and first_fused:            # its weight gradient came out of the second layer's data-gradient kernel
+                on_side(lambda ws: None, [wt.index, bt.index])
+                opt_bucket(i)
+                continue
             on_side(lambda ws, a=acts[i], go=g_out, nd=nd, wt=wt, bt=bt: ops.conv2d_bwd_weight(
                 a, go, nd["cout"], nd["k"], nd["stride"], nd["pt"], nd["pl"], dw=self.view(wt, self.grad),
                 dbias=self.view(bt, self.grad), ws=ws), [wt.index, bt.index])
             if i == 0:
                 opt_bucket(i)
                 continue                          # no gradient w.r.t. the image
+            if (i == 1 and self.fuse_first and not written[1] and self.nodes[0]["kind"] == "conv" and self.nodes[0]["cin"] == 8
+                    and self.nodes[0]["cout"] == 64 and nd["cin"] == 64 and nd["cout"] == 64 and nd["k"] == 3 and nd["stride"] == 1
+                    and nd["pt"] == 1 and nd["pl"] == 1 and self.nodes[0]["k"] == 3 and self.nodes[0]["stride"] == 1
+                    and self.relu_bits is not None and 1 in self.bits_valid):
+                wt0, bt0 = self.conv_params[0]
+                try:
+                    ops.conv2d_bwd_data_wgrad_first(g_out, self.w_t[1], c["rbits"][1], acts[0], dw=self.view(wt0, self.grad),
+                                                    dbias=self.view(bt0, self.grad), ws=self._ws)
+                    first_fused = True
+                    written[1] = True             # (consumed in the kernel: gacts[1] is not written)
+                    opt_bucket(i)
+                    continue
+                except NotImplementedError:       # SSD_ERR_UNSUPPORTED: nothing was launched
+                    self.fuse_first = False
             prev_is_relu_conv = self.nodes[i - 1]["kind"] == "conv"
             if i in head_done:                    # a large head wrote gacts[i] on the side stream: accumulate after it
                 main.wait_event(head_done.pop(i))

@@ -490,6 +490,29 @@ def conv2d_bwd_data_bits(dy, w_t, bits, x_shape, stride, pad_t, pad_l, accumulat
     return out
 
 
+def conv2d_bwd_data_wgrad_first(dy, w_t, bits, image, dw=None, dbias=None, ws=None):
+    """Data gradient of the second trunk layer (64 -> 64) fused with the weight gradient of the first (image -> 64): returns
+    (dw0 [64,3,3,8] f32, dbias0 [64] f32); the gradient w.r.t. the first layer's output is consumed inside the kernel and never
+    stored.  Same result as conv2d_bwd_data_bits + conv2d_bwd_weight up to fp32 summation order."""
+    L = _lib.lib()
+    _bf(dy); _bf(w_t); _bf(image)
+    B, H, W, c = dy.shape
+    assert c == 64 and w_t.shape == (64, 3, 3, 64) and image.shape == (B, H, W, 8)
+    assert bits.dtype == torch.uint8 and bits.shape == (B, H, W, 8)
+    if dw is None:
+        dw = torch.empty((64, 3, 3, 8), dtype=torch.float32, device=dy.device)
+    if dbias is None:
+        dbias = torch.empty((64,), dtype=torch.float32, device=dy.device)
+    assert dw.dtype == torch.float32 and dw.numel() == 64 * 72 and dw.is_contiguous() and dbias.dtype == torch.float32
+    wbuf = (ws or _conv_ws).get(L.ssd_conv2d_bwd_data_wgrad_first_workspace_bytes(B, H, W), dy.device)
+    rc = L.ssd_conv2d_bwd_data_wgrad_first(_ptr(dy), _ptr(w_t), _ptr(bits), _ptr(image), _ptr(dw), _ptr(dbias), B, H, W, _ptr(wbuf),
+                                           wbuf.numel(), _stream())
+    if rc == _lib.SSD_ERR_UNSUPPORTED:
+        raise NotImplementedError("maps smaller than 16x16 take the two separate calls")
+    _lib.check(rc)
+    return dw, dbias
+
+
 def conv2d_bwd_data_unpool(dy, w_t, relu_src, pool_code, full_shape, out=None, ws=None):
     """conv2d_bwd_data (3x3 / stride 1 / pad 1) w.r.t. a pooled map followed by maxpool2x2_bwd_argmax, in one launch: returns the
     gradient of the map BEFORE the pooling ([B,Hf,Wf,Cin]).  Raises NotImplementedError (SSD_ERR_UNSUPPORTED, nothing launched)

@@ -407,3 +407,48 @@ def test_image_prep(ops):
     img = torch.rand((2, 30, 30, 3))
     out = ops.image_prep(img.cuda()).float().cpu()
     assert torch.equal(out[..., :3], ((img - 0.5) * 2).bfloat16().float()) and float(out[..., 3:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("case", [(2, 300, 300), (3, 37, 52), (1, 16, 16), (70, 24, 40)])
+def test_second_layer_dgrad_fused_with_first_layer_wgrad(ops, case):
+    """ssd_conv2d_bwd_data_wgrad_first (k_conv3x3_c64b<DGRAD, W0>): block1_conv2's data gradient multiplied with the image
+    patch in its store stage -- the gradient w.r.t. block1_conv1's output never reaches memory.  Against (a) the two separate
+    calls it replaces (same bf16 rounding of the intermediate: only the fp32 summation order differs) and (b) the fp32
+    reference of the composition.  Cases: the real map (ragged right / bottom blocks, several blocks per workgroup), an odd
+    map, a single block, and more blocks than the 512 persistent workgroups at a small size; bitwise reproducible."""
+    B, H, W = case
+    g = torch.Generator().manual_seed(31 + H)
+    img = torch.zeros((B, H, W, 8)).bfloat16()
+    img[..., :3] = torch.randn((B, H, W, 3), generator=g).bfloat16()
+    w0 = torch.zeros((64, 3, 3, 8)).bfloat16()
+    w0[..., :3] = (torch.randn((64, 3, 3, 3), generator=g) / np.sqrt(27)).bfloat16()
+    b0 = torch.randn((64,), generator=g) * 0.1
+    w1 = (torch.randn((64, 3, 3, 64), generator=g) / 24).bfloat16()
+    dy = torch.randn((B, H, W, 64), generator=g).bfloat16()
+    imd, w1d, dyd = img.cuda(), w1.cuda(), dy.cuda()
+    bits = torch.empty((B, H, W, 8), dtype=torch.uint8, device="cuda")
+    a1 = ops.conv2d_fwd_relubits(imd, w0.cuda(), b0.cuda(), 1, 1, 1, H, W, bits)
+    w1_t = ops.weight_transpose(w1d, 64)
+    dw, db = ops.conv2d_bwd_data_wgrad_first(dyd, w1_t, bits, imd)
+    torch.cuda.synchronize()
+    # (a) the two calls
+    dx = ops.conv2d_bwd_data_bits(dyd, w1_t, bits, (B, H, W, 64), 1, 1, 1)
+    dw2, db2 = ops.conv2d_bwd_weight(imd, dx, 64, 3, 1, 1, 1)
+    sw, sb = max(1.0, dw2.abs().max().item()), max(1.0, db2.abs().max().item())
+    assert (dw - dw2).abs().max().item() <= 2e-5 * sw * np.sqrt(B * H * W / 256), "vs the separate calls"
+    assert (db - db2).abs().max().item() <= 2e-5 * sb * np.sqrt(B * H * W / 256)
+    assert torch.count_nonzero(dw[..., 3:]).item() == 0, "pad channels carry no gradient"
+    # (b) fp32 reference: dX = conv_transpose(dy, w1) * (a1 > 0), rounded to bf16 as the kernels hold it; dW0 = corr(image, dX)
+    if B * H * W <= 200000:
+        a1r = a1.float().cpu()
+        xr = a1r.clone().requires_grad_(True)
+        ref_conv(xr, w1.float(), None, 3, 1, 1, 1, H, W, False).backward(dy.float())
+        dxr = (xr.grad * (a1r > 0)).bfloat16().float()
+        wr = w0.float().requires_grad_(True)
+        br = b0.clone().requires_grad_(True)
+        ref_conv(img.float(), wr, br, 3, 1, 1, 1, H, W, False).backward(dxr)
+        # (a bf16 rounding of dX that falls the other way in the kernel moves one term by 2^-8 of its value)
+        assert (dw.cpu() - wr.grad).abs().max().item() <= 2e-3 * max(1.0, wr.grad.abs().max().item())
+        assert (db.cpu() - br.grad).abs().max().item() <= 2e-3 * max(1.0, br.grad.abs().max().item())
+    dw3, db3 = ops.conv2d_bwd_data_wgrad_first(dyd, w1_t, bits, imd)
+    assert torch.equal(dw, dw3) and torch.equal(db, db3)

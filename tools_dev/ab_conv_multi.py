@@ -34,6 +34,14 @@ for spec in sys.argv[1:]:
         dw, db = ops.conv2d_bwd_weight(x, dy, Cout, k, S, pt, pt)
         run = lambda: ops.conv2d_bwd_weight(x, dy, Cout, k, S, pt, pt, dw=dw, dbias=db)
         plan = lambda: L.ssd_conv2d_bwd_weight_plan(B, H, H, Cin, Cout, cp, k, S, pt, pt, Ho, Ho)
+    elif mode == "w0fused":                         # second layer's data gradient + first layer's weight gradient, one kernel
+        dy = torch.randn((B, H, H, 64), device="cuda").bfloat16()
+        w_t = (torch.randn((64, 3, 3, 64), device="cuda") * 0.05).bfloat16()
+        img = torch.zeros((B, H, H, 8), device="cuda").bfloat16(); img[..., :3] = torch.randn((B, H, H, 3), device="cuda").bfloat16()
+        bits = torch.randint(0, 256, (B, H, H, 8), device="cuda", dtype=torch.uint8)
+        dw, db = ops.conv2d_bwd_data_wgrad_first(dy, w_t, bits, img)
+        run = lambda: ops.conv2d_bwd_data_wgrad_first(dy, w_t, bits, img, dw=dw, dbias=db)
+        plan = lambda: -1
     elif mode == "dgradbits":                       # the data gradient as the engine calls it: ReLU mask as sign bits
         dy = torch.zeros((B, Ho, Ho, cp), device="cuda").bfloat16(); dy[..., :Cout] = torch.randn((B, Ho, Ho, Cout), device="cuda").bfloat16()
         w_t = (torch.randn((Cin, k, k, cp), device="cuda") * 0.05).bfloat16()
@@ -66,6 +74,6 @@ for spec in sys.argv[1:]:
     for v in vals:
         L.ssd_dev_knob(knob.encode(), v)
         a = sorted(t[v])
-        out.append("%s=%d [%s] %.1f us %.0f TF/s" % (knob, v, plan_name(L, plan()), a[len(a) // 2], fl / a[len(a) // 2] / 1e6))
+        out.append("%s=%d [%s] %.1f us %.0f TF/s" % (knob, v, (plan_name(L, plan()) if plan() >= 0 else "fused"), a[len(a) // 2], fl / a[len(a) // 2] / 1e6))
     L.ssd_dev_knob(knob.encode(), vals[0])
     print("%-5s B%d %dx%d %d->%d k%d s%d: " % (mode, B, H, H, Cin, Cout, k, S) + " | ".join(out), flush=True)

@@ -1025,7 +1025,9 @@ constexpr int C64B_PATCH_PIX = (C64B_ROWS + 2) * PATCH_W;  // 180 halo pixels
 constexpr int C64B_NDMA = (C64B_PATCH_PIX * 10 + 63) / 64; // 29 wave-instructions of 64 x 16 B
 constexpr int C64B_PATCH = C64B_NDMA * 1024;               // 29696 B per buffer
 constexpr int C64B_STAGE = 2 * C64B_PATCH;                 // [128 px][64 ch] bf16 staging tile (16 KB)
-constexpr int C64B_LDS = C64B_STAGE + 128 * 128;
+constexpr int C64B_FRAG_DEPTH = 3;                          // fragment reads run two steps ahead (four and six: measured, no faster)
+constexpr int C64B_BIAS = C64B_STAGE + 128 * 128;          // forward: the 64 biases (the accumulators start from them)
+constexpr int C64B_LDS = C64B_BIAS + 256;
 
 // W0 form (block1_conv2's data gradient + block1_conv1's weight gradient in one kernel).  The gradient this layer produces has
 // exactly one consumer -- the weight gradient of the 3-channel first layer, dW0[co][tap][ci] = sum_px dX[px][co] * img[px +
@@ -1132,18 +1134,42 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
             }
     }
     const int xbase = (4 * wave_m * PATCH_W + frow) * C64_PITCH + fk * 16;
+    // forward: the bias is the accumulators' initial value (from LDS, written once here; the first barrier of the block loop
+    // publishes it) -- fetched in the epilogue it was a global round trip per block with the matrix cores idle
+    if constexpr (EPI == EPI_FWD) {
+        if (tid < 64) reinterpret_cast<float*>(smem + C64B_BIAS)[tid] = (ep.bias && tid < g.N) ? ep.bias[tid] : 0.f;
+    }
     if constexpr (W0) {                                     // this wave's running sums (no other wave touches them)
         f32x4_t* sums = reinterpret_cast<f32x4_t*>(smem + C64B_W0_SUMS) + wave * 3 * 64 + lane;
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt) sums[nt * 64] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
 
+    // W0: mkn[p] = the four sign bytes of this wave's 32 channels at the lane's pixel of accumulator row p of block t (block row
+    // 4 wave_m + p, column lane & 15); 0 outside the map
+    unsigned mkn[4] = {0u, 0u, 0u, 0u};
+    auto load_masks = [&](int t) {
+        int r = t;
+        const int tx = r % tiles_x; r /= tiles_x;
+        const int ty = r % tiles_y;
+        const int b = r / tiles_y;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int y = ty * C64B_ROWS + 4 * wave_m + p, xx = tx * 16 + (lane & 15);
+            mkn[p] = 0u;
+            if (y < g.Ho && xx < g.Wo)
+                mkn[p] = *reinterpret_cast<const unsigned*>(ep.mask_bits + (long long)((b * g.Ho + y) * g.Wo + xx) * 8 + wave_n * 4);
+        }
+    };
+    if constexpr (W0) { if (block_of(0) >= 0) load_masks(block_of(0)); }
+
     int it = 0, prev_st = 0;
     for (int t = block_of(0); t >= 0; t = block_of(++it)) {
         const int cur = it & 1;
         // this block's patch (issued one block ago) is older than the epilogue stores issued since: wait for all but those
         // (prev_st = wave-uniform lower bound of the store instructions the previous epilogue issued)
-        if (prev_st >= 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        if (g.ablate & 2) {}                                // (timing experiment, development builds: do not wait for the patch)
+        else if (prev_st >= 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
         else if (prev_st == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
         else if (prev_st == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         else if (prev_st == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
@@ -1171,7 +1197,13 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
             return (y < g.Ho && xx < g.Wo) ? (b * g.Ho + y) * g.Wo + xx : -1;
         };
         const bool premask = EPI == EPI_DGRAD && ep.mask_bits != nullptr && !(g.ablate & 128);
-        if constexpr (EPI == EPI_DGRAD) {
+        if constexpr (W0) {
+            // W0 form: the mask is applied to the accumulators themselves (the masked tile feeds the weight-gradient MFMAs from
+            // LDS: no second pass over it) and travels one block ahead like the patch: the wait at the top of the loop has
+            // covered it, the epilogue waits for no memory operation at all
+#pragma unroll
+            for (int p = 0; p < 4; ++p) mk[p] = mkn[p];
+        } else if constexpr (EPI == EPI_DGRAD) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = chunk_pixel(tid, i);
@@ -1181,21 +1213,29 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
         }
         const int tnext = block_of(it + 1);
         if (tnext >= 0 && !(g.ablate & 1)) issue_patch(tnext, cur ^ 1);
+        if constexpr (W0) { if (tnext >= 0) load_masks(tnext); }
         const int pb = cur * C64B_PATCH + xbase;
         f32x4_t acc[2][4];
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < 2; ++c) {
+            f32x4_t a0 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if constexpr (EPI == EPI_FWD)
+                a0 = *reinterpret_cast<const f32x4_t*>(smem + C64B_BIAS + (wave_n * 32 + c * 16 + (lane >> 4) * 4) * 4);
 #pragma unroll
-            for (int p = 0; p < 4; ++p) acc[c][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int p = 0; p < 4; ++p) acc[c][p] = a0;
+        }
         // step s = (patch row rr = s / 6, dx = (s / 2) % 3, k-half = s & 1)
         auto frag = [&](int s2) {
             return *reinterpret_cast<const bf16x8_t*>(smem + pb + ((s2 / 6) * PATCH_W + (s2 / 2) % 3) * C64_PITCH + (s2 & 1) * 64);
         };
-        bf16x8_t f0 = frag(0), f1 = frag(1);
+        // fragment ring: the read of step s2 + FD - 1 is issued at the start of step s2 (into the slot step s2 - 1 used)
+        constexpr int FD = C64B_FRAG_DEPTH;
+        bf16x8_t fr[FD];
+#pragma unroll
+        for (int i = 0; i < FD - 1; ++i) fr[i] = frag(i);
 #pragma unroll
         for (int s2 = 0; s2 < 36; ++s2) {
-            bf16x8_t f2 = f1;
-            if (s2 + 2 < 36) f2 = frag(s2 + 2);
+            if (s2 + FD - 1 < 36) fr[(s2 + FD - 1) % FD] = frag(s2 + FD - 1);
             const int rr = s2 / 6, dx = (s2 / 2) % 3, ks = s2 & 1;
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
@@ -1203,11 +1243,10 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
                 if (p >= 0 && p < 4) {
 #pragma unroll
                     for (int c = 0; c < 2; ++c)
-                        acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[c][dy * 3 + dx][ks], f0, acc[c][p], 0, 0, 0);
+                        acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[c][dy * 3 + dx][ks], fr[s2 % FD], acc[c][p], 0, 0, 0);
                 }
             }
-            f0 = f1; f1 = f2;
-            __builtin_amdgcn_sched_barrier(0);              // keep the reads two steps ahead, no further (144 VGPRs of weights)
+            __builtin_amdgcn_sched_barrier(0);              // keep the reads FD - 1 steps ahead, no further (144 VGPRs of weights)
         }
         if (g.ablate & 8) {
 #pragma unroll
@@ -1228,28 +1267,31 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
         if constexpr (W0) {
             // (the host only launches this form with sign bits: premask holds)
             char* st = smem + cur * C64B_PATCH;             // staging tile [128 px][64 ch] over the patch every wave is done with
-            __syncthreads();
+            // (bare barriers: __syncthreads() would also wait for the next block's patch, the LDS-DMA in flight)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            int t2 = tid;
+            asm volatile("" : "+v"(t2));                     // (opaque copy: indices are recomputed here, not held across the MFMA phase)
+            {
+                const int l3 = t2 & 63;
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int col = wave_n * 32 + c * 16 + (lane >> 4) * 4;
+                for (int c = 0; c < 2; ++c) {
+                    const int col = wave_n * 32 + c * 16 + (l3 >> 4) * 4;
+                    const int sh = 8 * (2 * c + (l3 >> 5)) + 4 * ((l3 >> 4) & 1);   // this lane's four sign bits within mk[p]
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int row = wave_m * 64 + p * 16 + (lane & 15);
-                    *reinterpret_cast<uint2*>(st + row * 128 + ((((col >> 3) ^ row) & 7) << 4) + (col & 4) * 2) =
-                        make_uint2((unsigned)f2bf(acc[c][p][0]) | ((unsigned)f2bf(acc[c][p][1]) << 16),
-                                   (unsigned)f2bf(acc[c][p][2]) | ((unsigned)f2bf(acc[c][p][3]) << 16));
+                    for (int p = 0; p < 4; ++p) {
+                        const int row = wave_m * 64 + p * 16 + (l3 & 15);
+                        const unsigned bits = mk[p] >> sh;
+                        const unsigned k0 = ((bits & 1u) ? 0x0000ffffu : 0u) | ((bits & 2u) ? 0xffff0000u : 0u);
+                        const unsigned k1 = ((bits & 4u) ? 0x0000ffffu : 0u) | ((bits & 8u) ? 0xffff0000u : 0u);
+                        lds_st8_scoped(st + row * 128 + ((((col >> 3) ^ row) & 7) << 4) + (col & 4) * 2, smem,
+                            make_uint2(((unsigned)f2bf(acc[c][p][0]) | ((unsigned)f2bf(acc[c][p][1]) << 16)) & k0,
+                                       ((unsigned)f2bf(acc[c][p][2]) | ((unsigned)f2bf(acc[c][p][3]) << 16)) & k1));
+                    }
                 }
             }
-            __syncthreads();
-            int t2 = tid;
-            asm volatile("" : "+v"(t2));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {                   // ReLU mask in place (pixels outside the map: mk = 0, i.e. zeros)
-                const int idx = i * 256 + t2, row = idx >> 3, ch = idx & 7;
-                uint4* slot = reinterpret_cast<uint4*>(st + row * 128 + (((ch ^ row) & 7) << 4));
-                *slot = gate_bits8(*slot, mk[i]);
-            }
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
             // dW0 tile of this wave: D[co = 16 wave + 4 (lane >> 4) + j][column = lane & 15] over the 128 pixels of the block.
             // MFMA k index 8 g + e of k-step s  <->  block pixel 32 s + 8 g + e (row 2 s + (g >> 1), column 8 (g & 1) + e); both
             // operands come through the transposing read: lane 4 q + p of a 16-lane group supplies the address of k row q (+ 4
@@ -1272,7 +1314,10 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
             f32x4_t* sums = reinterpret_cast<f32x4_t*>(smem + C64B_W0_SUMS) + wave * 3 * 64 + l2;
             f32x4_t aw[3];
 #pragma unroll
-            for (int nt = 0; nt < 3; ++nt) aw[nt] = sums[nt * 64];
+            for (int nt = 0; nt < 3; ++nt) {
+                const uint4 u = lds_ld16_scoped(reinterpret_cast<const char*>(sums + nt * 64), smem);
+                aw[nt] = f32x4_t{__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)};
+            }
             bf16x8_t ones;
 #pragma unroll
             for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
@@ -1291,34 +1336,64 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
                 }
             }
 #pragma unroll
-            for (int nt = 0; nt < 3; ++nt) sums[nt * 64] = aw[nt];
+            for (int nt = 0; nt < 3; ++nt)
+                lds_st16_scoped(reinterpret_cast<char*>(sums + nt * 64), smem,
+                                make_uint4(__float_as_uint(aw[nt][0]), __float_as_uint(aw[nt][1]), __float_as_uint(aw[nt][2]), __float_as_uint(aw[nt][3])));
             prev_st = 0;                                    // nothing was stored: only the DMA is in flight
             continue;
         }
-        if (premask) {
+        // The staging tile has its own LDS here and the barrier at the top of the block loop already separates one block's
+        // reads of it from the next block's writes: ONE barrier per epilogue, and a bare one -- __syncthreads() also waits for
+        // every LDS-DMA in flight (s_waitcnt vmcnt(0)), i.e. for the next block's patch, in the middle of the epilogue.
+        if constexpr (EPI == EPI_FWD) {
+            char* st = smem + C64B_STAGE;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int col = wave_n * 32 + c * 16 + (lane >> 4) * 4;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int row = wave_m * 64 + p * 16 + (lane & 15);
+                    float v[4] = {acc[c][p][0], acc[c][p][1], acc[c][p][2], acc[c][p][3]};
+                    if (ep.relu) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                    }
+                    lds_st8_scoped(st + row * 128 + ((((col >> 3) ^ row) & 7) << 4) + (col & 4) * 2, smem,
+                        make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16)));
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            int t2 = tid;
+            asm volatile("" : "+v"(t2));                     // (opaque copy: the store stage recomputes its indices instead of holding them across the MFMA phase)
+            staged_store<EPI_FWD, 128, 64, 256, decltype(row_to_m), decltype(pool_index)>(st, g, ep, 0, t2, row_to_m, pool_index);
+        } else if (premask) {
             if constexpr (EPI == EPI_DGRAD) {               // staged_epilogue's data-gradient path with the mask already here
                 char* st = smem + C64B_STAGE;
-                __syncthreads();
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const int col = wave_n * 32 + c * 16 + (lane >> 4) * 4;
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
                         const int row = wave_m * 64 + p * 16 + (lane & 15);
-                        *reinterpret_cast<uint2*>(st + row * 128 + ((((col >> 3) ^ row) & 7) << 4) + (col & 4) * 2) =
+                        lds_st8_scoped(st + row * 128 + ((((col >> 3) ^ row) & 7) << 4) + (col & 4) * 2, smem,
                             make_uint2((unsigned)f2bf(acc[c][p][0]) | ((unsigned)f2bf(acc[c][p][1]) << 16),
-                                       (unsigned)f2bf(acc[c][p][2]) | ((unsigned)f2bf(acc[c][p][3]) << 16));
+                                       (unsigned)f2bf(acc[c][p][2]) | ((unsigned)f2bf(acc[c][p][3]) << 16)));
                     }
                 }
-                __syncthreads();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
                 int t2 = tid;
                 asm volatile("" : "+v"(t2));                 // (opaque copy: keeps the compiler from carrying the indices over from above)
+                // the masks are consumed HERE, in uniform control flow: left to the divergent chunks below, the wait for them was
+                // re-issued at every join as s_waitcnt vmcnt(0) -- which also waits for the chunk store just issued
+                asm volatile("" : "+v"(mk[0]), "+v"(mk[1]), "+v"(mk[2]), "+v"(mk[3]));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int idx = i * 256 + t2, row = idx >> 3, ch = idx & 7;
                     const int m = chunk_pixel(t2, i);
                     if (m < 0) continue;
-                    uint4 v = *reinterpret_cast<const uint4*>(st + row * 128 + (((ch ^ row) & 7) << 4));
+                    uint4 v = lds_ld16_scoped(st + row * 128 + (((ch ^ row) & 7) << 4), smem);
                     v = gate_bits8(v, mk[i]);
                     *reinterpret_cast<uint4*>(ep.out + (long long)m * ep.ldo + ch * 8) = v;
                 }
@@ -2541,7 +2616,8 @@ Knob g_knobs[] = {{"SSD_ABLATE", {KNOB_UNSET}}, {"SSD_DGRAD_S2", {KNOB_UNSET}},
                   {"SSD_WGRAD_PATCH_SHAPE", {KNOB_UNSET}}, {"SSD_WGRAD_TILE", {KNOB_UNSET}},
                   {"SSD_CONV_PATCH_FLAT", {KNOB_UNSET}}, {"SSD_WGRAD_FIRST", {KNOB_UNSET}}, {"SSD_CONV_FIRST", {KNOB_UNSET}},
                   {"SSD_WGRAD_PATCH_XCD", {KNOB_UNSET}}, {"SSD_CONV_C64", {KNOB_UNSET}}, {"SSD_CONV_POOL_FUSE", {KNOB_UNSET}},
-                  {"SSD_CONV_PATCH_ROWFLAT", {KNOB_UNSET}}, {"SSD_MATCH_FUSED", {KNOB_UNSET}}, {"SSD_CONV_P512", {KNOB_UNSET}}};
+                  {"SSD_CONV_PATCH_ROWFLAT", {KNOB_UNSET}}, {"SSD_MATCH_FUSED", {KNOB_UNSET}}, {"SSD_CONV_P512", {KNOB_UNSET}},
+                  {"SSD_C64B_WGS", {KNOB_UNSET}}};
 Knob* find_knob(const char* name) {
     for (Knob& k : g_knobs) if (!strcmp(k.name, name)) return &k;
     return nullptr;
@@ -2583,7 +2659,8 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
             auto kern = k_conv3x3_c64b<EPI, false>;
             SSD_PLAN(SSD_PLAN_C64B | ((pooled && ep.pool_out) ? SSD_PLAN_F_POOL_FUSED : 0));
             static OnceLds set; if (ensure_lds(set, reinterpret_cast<const void*>(kern), (int)(C64B_LDS)) != 0) return SSD_ERR_LAUNCH;
-            hipLaunchKernelGGL(kern, dim3((unsigned)(nblocks < 512 ? nblocks : 512)), dim3(256), C64B_LDS, s, xp, wp, g, ep, tiles_x, tiles_y, C64W0{});
+            const int maxwg = knob("SSD_C64B_WGS", 512);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(nblocks < maxwg ? nblocks : maxwg)), dim3(256), C64B_LDS, s, xp, wp, g, ep, tiles_x, tiles_y, C64W0{});
             if (pooled && ep.pool_out) *pooled = true;
             return ssd_launch_status();
         }

@@ -258,6 +258,23 @@ __device__ __forceinline__ bool staged_ok(const ConvGeom& g, const Epilogue& ep)
 
 struct NoPool { __device__ long long operator()(int, int) const { return -1; } };
 
+// LDS accesses that carry an alias scope (the __restrict__ pair, inlined).  The compiler's waitcnt pass puts s_waitcnt vmcnt(0)
+// in front of every LDS access WITHOUT scope information while an LDS-DMA is in flight -- in a persistent kernel that
+// prefetches its next block by DMA (k_conv3x3_c64b) that is a wait for the next block's patch in the middle of the epilogue.
+// The kernels order DMA and LDS accesses themselves (counted s_waitcnt + barrier); elsewhere the scope changes nothing.
+__device__ __forceinline__ uint4 lds_ld16_scoped(const char* __restrict__ p, const char* __restrict__ other) {
+    (void)other;
+    return *reinterpret_cast<const uint4*>(p);
+}
+__device__ __forceinline__ void lds_st16_scoped(char* __restrict__ p, const char* __restrict__ other, uint4 v) {
+    (void)other;
+    *reinterpret_cast<uint4*>(p) = v;
+}
+__device__ __forceinline__ void lds_st8_scoped(char* __restrict__ p, const char* __restrict__ other, uint2 v) {
+    (void)other;
+    *reinterpret_cast<uint2*>(p) = v;
+}
+
 // Second half of the staged epilogue: the [BM px][BN ch] bf16 tile image in LDS (layout above; FWD: bias and ReLU already
 // applied) leaves as whole 16-byte chunks of contiguous rows; DGRAD applies accumulate / ReLU mask here, FWD the fused pooling.
 // Caller: a barrier between the last write of the image and this call.
@@ -353,7 +370,7 @@ __device__ __forceinline__ void staged_store(char* smem, const ConvGeom& g, cons
                     if (!ok[j]) continue;
                     const int row = rr[j], ch = cc[j], m = mm[j];
                     const int n = n0 + ch * 8;
-                    uint4 v = *reinterpret_cast<const uint4*>(smem + row * (BN * 2) + (((ch ^ row) & (CPR - 1)) << 4));
+                    uint4 v = lds_ld16_scoped(smem + row * (BN * 2) + (((ch ^ row) & (CPR - 1)) << 4), smem);
                     if (ep.accumulate) {                          // out += result (two gradients meet at a feature map)
                         auto add2 = [](unsigned a, unsigned b) {
                             const float lo = __uint_as_float(a << 16) + __uint_as_float(b << 16);
@@ -404,7 +421,7 @@ __device__ __forceinline__ void staged_store(char* smem, const ConvGeom& g, cons
             const int n = n0 + ch * 8;
             const int m = row_to_m(row);
             if (m < 0 || n >= g.N) continue;
-            uint4 v = *reinterpret_cast<const uint4*>(smem + row * (BN * 2) + (((ch ^ row) & (CPR - 1)) << 4));
+            uint4 v = lds_ld16_scoped(smem + row * (BN * 2) + (((ch ^ row) & (CPR - 1)) << 4), smem);
             const long long o = (long long)m * ep.ldo + n;
             if constexpr (EPI == EPI_DGRAD) {
                 if (ep.accumulate) {                          // out += result (two gradients meet at a feature map)
@@ -477,7 +494,7 @@ __device__ __forceinline__ void staged_store(char* smem, const ConvGeom& g, cons
                         for (int q = 0; q < 4; ++q) {
                             const int row = (2 * py + (q >> 1)) * 16 + 2 * px + (q & 1);
                             cand[q] = make_uint4(0, 0, 0, 0);      // a position outside the map never wins: 0 only ties with 0 = dead
-                            if (row_to_m(row) >= 0) cand[q] = *reinterpret_cast<const uint4*>(smem + row * (BN * 2) + (((ch ^ row) & (CPR - 1)) << 4));
+                            if (row_to_m(row) >= 0) cand[q] = lds_ld16_scoped(smem + row * (BN * 2) + (((ch ^ row) & (CPR - 1)) << 4), smem);
                         }
                         unsigned o4[4], cw = 0;
                         const us2 one = {1, 1}, four = {4, 4};
@@ -511,7 +528,7 @@ __device__ __forceinline__ void staged_store(char* smem, const ConvGeom& g, cons
                         for (int dx = 0; dx < 2; ++dx) {
                             const int row = (2 * py + dy) * 16 + 2 * px + dx;
                             if (row_to_m(row) < 0) continue;
-                            const uint4 v = *reinterpret_cast<const uint4*>(smem + row * (BN * 2) + (((ch ^ row) & (CPR - 1)) << 4));
+                            const uint4 v = lds_ld16_scoped(smem + row * (BN * 2) + (((ch ^ row) & (CPR - 1)) << 4), smem);
                             const unsigned wds[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                             for (int k = 0; k < 8; ++k) {

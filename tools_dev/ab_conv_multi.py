@@ -9,6 +9,9 @@ if os.environ.get('AB_LIB'):
     _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ['AB_LIB'])      # dev: time another build of the library
 from tests.conv_cases import plan_name
 L = _lib.lib()
+for kv in os.environ.get('AB_PRESET', '').split():          # other development knobs held fixed: "NAME=value ..."
+    k_, v_ = kv.split('=')
+    L.ssd_dev_knob(k_.encode(), int(v_))
 torch.manual_seed(0)
 for spec in sys.argv[1:]:
     mode, B, H, Cin, Cout, k, S, knob, vals = spec.split()

@@ -1534,8 +1534,10 @@ __global__ __launch_bounds__(512) void k_conv0_fwd(const bf16_raw* __restrict__ 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
                 }
-                *reinterpret_cast<uint2*>(stage + frow * 128 + (((c * 2 + (fk >> 1)) ^ (frow & 7)) << 4) + (fk & 1) * 8) =
-                    make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+                // (scoped: a plain LDS store here waits for the next block's patch DMA and, with it, for every store of the
+                //  previous row -- s_waitcnt vmcnt(0) twice per block in a kernel that lives on its stores)
+                lds_st8_scoped(stage + frow * 128 + (((c * 2 + (fk >> 1)) ^ (frow & 7)) << 4) + (fk & 1) * 8, smem,
+                    make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16)));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave wrote it: no barrier needed
             const int y = y0 + row;
@@ -1543,7 +1545,7 @@ __global__ __launch_bounds__(512) void k_conv0_fwd(const bf16_raw* __restrict__ 
             for (int h = 0; h < 2; ++h) {
                 const int idx = h * 64 + lane;
                 const int px = idx >> 3, ch = idx & 7;
-                const uint4 v = *reinterpret_cast<const uint4*>(stage + px * 128 + ((ch ^ (px & 7)) << 4));
+                const uint4 v = lds_ld16_scoped(stage + px * 128 + ((ch ^ (px & 7)) << 4), smem);
                 const int xx = x0 + px;
                 if (y < g.Ho && xx < g.Wo) {        // N == 64 (host check): every chunk of the pixel is stored
                     *reinterpret_cast<uint4*>(out + ((unsigned)((b * g.Ho + y) * g.Wo + xx) * 64u + (unsigned)(ch * 8))) = v;

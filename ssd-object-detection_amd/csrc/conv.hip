@@ -2705,9 +2705,12 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
             // 512 px x 128 channels, one workgroup per CU: from 256 input channels on (eight 32-channel chunks amortise its longer
             // prologue / epilogue; measured per layer in DESIGN.md section 9).  SSD_CONV_P512: 0 never, 1 (default) that rule, 2 always
             const int p512 = knob("SSD_CONV_P512", 1);
-            // (the heads' element-wise scatter epilogue has nothing to hide behind with one workgroup per CU: head 0, 38x38 x 512
-            //  channels, 385 vs 334 us; head 1, 1024 channels, 208 vs 222 us -- the 512-pixel kernel from 1024 channels on)
-            if (p512 && g.C % 64 == 0 && g.N > 64 && (p512 >= 2 || g.C >= (EPI == EPI_HEAD ? 1024 : 256))) {
+            // (the heads never take it.  Head 0, 38x38 x 512 channels: its element-wise scatter epilogue has nothing to hide
+            //  behind with one workgroup per CU, 385 vs 334 us.  Head 1, 19x19 x 1024 channels, is 208 vs 222 us ALONE -- but it
+            //  runs beside the extras' chain of small launches, and a 512-pixel workgroup holds 152 of the CU's 160 KB of LDS:
+            //  not one of those launches (64 KB each) found a CU until it had drained, 190 us for a 15-GFLOP layer and the
+            //  loss 130 us later.  With the 78 KB workgroups of the patch kernel the two overlap: -0.07 ms per step.)
+            if (p512 && g.C % 64 == 0 && g.N > 64 && (p512 >= 2 || (EPI != EPI_HEAD && g.C >= 256))) {
                 const int ty32 = (g.Ho + 31) / 32;
                 const unsigned strips32 = (unsigned)(((long long)g.B * (g.H + 1) + 31) / 32);
                 const int rf = (!flat && !ep.pool_out && knob("SSD_CONV_PATCH_ROWFLAT", 1) && strips32 < (unsigned)(ty32 * g.B)) ? 1 : 0;
@@ -3016,7 +3019,7 @@ int ssd_conv2d_bwd_data_wgrad_first(const void* dy, const void* w_t, const void*
     ep.mask_bits = static_cast<const unsigned char*>(relu_bits);
     const int tiles_x = (W + 15) / 16, tiles_y = (H + C64B_ROWS - 1) / C64B_ROWS;
     const int nblocks = B * tiles_x * tiles_y;
-    const unsigned grid = (unsigned)(nblocks < 512 ? nblocks : 512);
+    const unsigned grid = (unsigned)(nblocks < 512 ? nblocks : 512);   // (one workgroup per CU, to run beside the next weight gradient: slower)
     float* slab_w = static_cast<float*>(ws);
     float* slab_b = slab_w + (size_t)512 * 64 * 72;
     hipStream_t s = (hipStream_t)stream;

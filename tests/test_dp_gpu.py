@@ -149,3 +149,56 @@ def test_train_cli_two_ranks_equal_split_batch(tmp_path):
     diff = np.abs(res[0][1] - ref)
     assert moved > 1e-4
     assert float(diff.mean()) < 2e-7 and float((diff > 2e-6).mean()) < 0.03 and diff.max() <= 0.5 * moved
+
+
+def _nccl_rank_main(port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from ssd_object_detection_amd import optimizers
+    from ssd_object_detection_amd.models import SSDObjectDetectionModel
+    model = SSDObjectDetectionModel(classes=80, log_dir="gpurun_out/dp_test", seed=5, distributed=True, timestamp_dir=False)
+    imgs, cls_l, box_l = _make_inputs(model)
+    image, (cls, loc, mask) = model.make_batch(imgs, cls_l, box_l)
+    opt = optimizers.Adam(1e-3)
+    for _ in range(2):
+        model._train_step(image, cls, loc, mask, opt)
+    torch.cuda.synchronize()
+    q.put(model.get_engine().param.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_single_rank_equals_the_local_step():
+    """The distributed train step on the `nccl` backend (RCCL): the one-GPU pool cannot hold two RCCL ranks, but a
+    communicator of ONE rank runs every call the N-rank job makes -- bucketed asynchronous all-reduce of the flat fp32
+    gradient on the exchange stream, the per-bucket optimizer behind it, the events between the three streams -- and must
+    reproduce the non-distributed step (sum over one rank, scale 1 / world = 1): two steps, parameters compared."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_rank_main, args=(port, q))
+    p.start()
+    dp_param = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+
+    from ssd_object_detection_amd import optimizers
+    from ssd_object_detection_amd.models import SSDObjectDetectionModel
+    model = SSDObjectDetectionModel(classes=80, log_dir="gpurun_out/dp_test", seed=5, timestamp_dir=False)
+    p0 = model.get_engine().param.cpu().numpy().copy()
+    imgs, cls_l, box_l = _make_inputs(model)
+    image, (cls, loc, mask) = model.make_batch(imgs, cls_l, box_l)
+    opt = optimizers.Adam(1e-3)
+    for _ in range(2):
+        model._train_step(image, cls, loc, mask, opt)
+    ref = model.get_engine().param.cpu().numpy()
+    moved = np.abs(ref - p0).max()
+    assert moved > 1e-4
+    diff = np.abs(dp_param - ref)
+    # (the distributed step clips per tensor before the exchange and applies Adam per bucket: same arithmetic per element)
+    assert float(diff.mean()) < 1e-7 and float((diff > 1e-6).mean()) < 0.02 and diff.max() <= 0.5 * moved

@@ -1285,8 +1285,8 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
                         const unsigned k0 = ((bits & 1u) ? 0x0000ffffu : 0u) | ((bits & 2u) ? 0xffff0000u : 0u);
                         const unsigned k1 = ((bits & 4u) ? 0x0000ffffu : 0u) | ((bits & 8u) ? 0xffff0000u : 0u);
                         lds_st8_scoped(st + row * 128 + ((((col >> 3) ^ row) & 7) << 4) + (col & 4) * 2, smem,
-                            make_uint2(((unsigned)f2bf(acc[c][p][0]) | ((unsigned)f2bf(acc[c][p][1]) << 16)) & k0,
-                                       ((unsigned)f2bf(acc[c][p][2]) | ((unsigned)f2bf(acc[c][p][3]) << 16)) & k1));
+                            make_uint2((pack_bf16x2(acc[c][p][0], acc[c][p][1])) & k0,
+                                       (pack_bf16x2(acc[c][p][2], acc[c][p][3])) & k1));
                     }
                 }
             }
@@ -1359,7 +1359,7 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
                         for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
                     }
                     lds_st8_scoped(st + row * 128 + ((((col >> 3) ^ row) & 7) << 4) + (col & 4) * 2, smem,
-                        make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16)));
+                        make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])));
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1377,8 +1377,8 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
                     for (int p = 0; p < 4; ++p) {
                         const int row = wave_m * 64 + p * 16 + (lane & 15);
                         lds_st8_scoped(st + row * 128 + ((((col >> 3) ^ row) & 7) << 4) + (col & 4) * 2, smem,
-                            make_uint2((unsigned)f2bf(acc[c][p][0]) | ((unsigned)f2bf(acc[c][p][1]) << 16),
-                                       (unsigned)f2bf(acc[c][p][2]) | ((unsigned)f2bf(acc[c][p][3]) << 16)));
+                            make_uint2(pack_bf16x2(acc[c][p][0], acc[c][p][1]),
+                                       pack_bf16x2(acc[c][p][2], acc[c][p][3])));
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1537,7 +1537,7 @@ __global__ __launch_bounds__(512) void k_conv0_fwd(const bf16_raw* __restrict__ 
                 // (scoped: a plain LDS store here waits for the next block's patch DMA and, with it, for every store of the
                 //  previous row -- s_waitcnt vmcnt(0) twice per block in a kernel that lives on its stores)
                 lds_st8_scoped(stage + frow * 128 + (((c * 2 + (fk >> 1)) ^ (frow & 7)) << 4) + (fk & 1) * 8, smem,
-                    make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16)));
+                    make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave wrote it: no barrier needed
             const int y = y0 + row;
@@ -2415,7 +2415,7 @@ __global__ void k_image_prep(const float* __restrict__ img, bf16_raw* __restrict
     float r = img[3 * i], gch = img[3 * i + 1], b = img[3 * i + 2];
     if (normalize) { r = (r - 0.5f) * 2.f; gch = (gch - 0.5f) * 2.f; b = (b - 0.5f) * 2.f; }
     *reinterpret_cast<uint4*>(out + 8 * i) =
-        make_uint4((unsigned)f2bf(r) | ((unsigned)f2bf(gch) << 16), (unsigned)f2bf(b), 0u, 0u);
+        make_uint4(pack_bf16x2(r, gch), (unsigned)f2bf(b), 0u, 0u);
 }
 
 // 2x2 stride-2 max pooling, NHWC bf16, 8 channels per thread.  pad_b/pad_r = 1 for TF "SAME" on odd sizes.

@@ -120,6 +120,14 @@ __device__ __forceinline__ uint4 gate_bits8(uint4 v, unsigned b) {
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// two floats -> two bf16 in one word (low half = a): ONE v_cvt_pk_bf16_f32 (the same round-to-nearest-even instruction that
+// f2bf() lowers to, so results are identical); composed from two f2bf() the compiler emitted two conversions, a shift and an or
+typedef __bf16 ssd_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float ssd_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    const ssd_f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, ssd_bf16x2_t));
+}
 __device__ __forceinline__ float bf2f(bf16_raw v) { return __uint_as_float((unsigned)v << 16); }
 __device__ __forceinline__ bf16_raw f2bf(float f) {
     const __hip_bfloat16 h = __float2bfloat16(f);
@@ -144,8 +152,8 @@ __device__ __forceinline__ void epi_store(float (&v)[4], int m, int n, bool full
         }
         bf16_raw* o = ep.out + (long long)m * ep.ldo + n;
         if (full) {
-            *reinterpret_cast<uint2*>(o) = make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16),
-                                                      (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+            *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(v[0], v[1]),
+                                                      pack_bf16x2(v[2], v[3]));
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) if (n + j < g.N) o[j] = f2bf(v[j]);
@@ -166,8 +174,8 @@ __device__ __forceinline__ void epi_store(float (&v)[4], int m, int n, bool full
                 if (!(__uint_as_float(mk.y << 16) > 0.f)) v[2] = 0.f;
                 if (!(__uint_as_float(mk.y & 0xffff0000u) > 0.f)) v[3] = 0.f;
             }
-            *reinterpret_cast<uint2*>(o) = make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16),
-                                                      (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+            *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(v[0], v[1]),
+                                                      pack_bf16x2(v[2], v[3]));
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -375,7 +383,7 @@ __device__ __forceinline__ void staged_store(char* smem, const ConvGeom& g, cons
                         auto add2 = [](unsigned a, unsigned b) {
                             const float lo = __uint_as_float(a << 16) + __uint_as_float(b << 16);
                             const float hi = __uint_as_float(a & 0xffff0000u) + __uint_as_float(b & 0xffff0000u);
-                            return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+                            return pack_bf16x2(lo, hi);
                         };
                         v.x = add2(v.x, old[j].x); v.y = add2(v.y, old[j].y); v.z = add2(v.z, old[j].z); v.w = add2(v.w, old[j].w);
                     }
@@ -429,7 +437,7 @@ __device__ __forceinline__ void staged_store(char* smem, const ConvGeom& g, cons
                     auto add2 = [](unsigned a, unsigned b) {
                         const float lo = __uint_as_float(a << 16) + __uint_as_float(b << 16);
                         const float hi = __uint_as_float(a & 0xffff0000u) + __uint_as_float(b & 0xffff0000u);
-                        return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+                        return pack_bf16x2(lo, hi);
                     };
                     v.x = add2(v.x, old.x); v.y = add2(v.y, old.y); v.z = add2(v.z, old.z); v.w = add2(v.w, old.w);
                 }
@@ -574,7 +582,7 @@ __device__ __forceinline__ void staged_epilogue(f32x4_t (&acc)[CT][PT], char* sm
                 }
             }
             *reinterpret_cast<uint2*>(smem + row * (BN * 2) + ((((col >> 3) ^ row) & (CPR - 1)) << 4) + (col & 4) * 2) =
-                make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+                make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
         }
     }
     __syncthreads();

@@ -210,8 +210,8 @@ __global__ __launch_bounds__(256) void k_hz_col2im(CArgs a) {
             acc[0] += v0[t].x; acc[1] += v0[t].y; acc[2] += v0[t].z; acc[3] += v0[t].w;
             acc[4] += v1[t].x; acc[5] += v1[t].y; acc[6] += v1[t].z; acc[7] += v1[t].w;
         }
-        uint4 v = make_uint4((unsigned)f2bf(acc[0]) | ((unsigned)f2bf(acc[1]) << 16), (unsigned)f2bf(acc[2]) | ((unsigned)f2bf(acc[3]) << 16),
-                             (unsigned)f2bf(acc[4]) | ((unsigned)f2bf(acc[5]) << 16), (unsigned)f2bf(acc[6]) | ((unsigned)f2bf(acc[7]) << 16));
+        uint4 v = make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]),
+                             pack_bf16x2(acc[4], acc[5]), pack_bf16x2(acc[6], acc[7]));
         const long long o = (long long)pixel * lv.Cin + cg * 8;
         if (lv.bits) {
             v = gate_bits8(v, mb[j]);

@@ -24,6 +24,9 @@ PER_FILE = {
     "detect.hip": ["-ffp-contract=off"],
     # the resize restates cv2's float arithmetic product by product (HIP's __fmul_rn / __fadd_rn are plain * and +)
     "prep.hip": ["-ffp-contract=off"],
+    # ReLU is fmaxf(x, 0): with NaNs honoured every one of them is preceded by the sNaN-quieting v_max(x, x) -- 1 800 vector
+    # instructions over the convolution epilogues, all on finite data
+    "conv.hip": ["-fno-honor-nans"],
 }
 
 

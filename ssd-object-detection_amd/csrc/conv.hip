@@ -1282,8 +1282,7 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
                     for (int p = 0; p < 4; ++p) {
                         const int row = wave_m * 64 + p * 16 + (l3 & 15);
                         const unsigned bits = mk[p] >> sh;
-                        const unsigned k0 = ((bits & 1u) ? 0x0000ffffu : 0u) | ((bits & 2u) ? 0xffff0000u : 0u);
-                        const unsigned k1 = ((bits & 4u) ? 0x0000ffffu : 0u) | ((bits & 8u) ? 0xffff0000u : 0u);
+                        const unsigned k0 = keep_mask2(bits, 0), k1 = keep_mask2(bits, 2);
                         lds_st8_scoped(st + row * 128 + ((((col >> 3) ^ row) & 7) << 4) + (col & 4) * 2, smem,
                             make_uint2((pack_bf16x2(acc[c][p][0], acc[c][p][1])) & k0,
                                        (pack_bf16x2(acc[c][p][2], acc[c][p][3])) & k1));

@@ -112,11 +112,17 @@ __device__ __forceinline__ unsigned relu_bits8(const uint4& v) {
     }
     return b;
 }
+// word mask of two sign bits: bit `pos` keeps the low bf16, bit `pos + 1` the high one (two sign-extending bit-field extracts
+// and one byte permute; written with selects it was six vector instructions per word in every data-gradient epilogue)
+__device__ __forceinline__ unsigned keep_mask2(unsigned bits, int pos) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_sbfe((int)bits, pos, 1), hi = (unsigned)__builtin_amdgcn_sbfe((int)bits, pos + 1, 1);
+    return __builtin_amdgcn_perm(hi, lo, 0x07060100u);      // bytes 0, 1 of lo; bytes 2, 3 of hi
+}
 // zero the elements of a chunk whose bit is clear
 __device__ __forceinline__ uint4 gate_bits8(uint4 v, unsigned b) {
     unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) w[k] &= ((b >> (2 * k)) & 1u ? 0x0000ffffu : 0u) | ((b >> (2 * k + 1)) & 1u ? 0xffff0000u : 0u);
+    for (int k = 0; k < 4; ++k) w[k] &= keep_mask2(b, 2 * k);
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 

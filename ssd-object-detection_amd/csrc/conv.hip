@@ -82,6 +82,12 @@ __device__ __attribute__((aligned(16))) const unsigned g_zero16[4] = {0u, 0u, 0u
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
 
+// (a device function, not a call inside the kernel's lambda: with the builtin written there clang's HOST pass silently emitted
+//  no stub for any instantiation of k_conv_igemm_dma -- an undefined symbol at load time, no diagnostic)
+__device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t r, char* lds, unsigned off) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)lds, 16, off, 0, 0, 0);
+}
+
 template <int BM, int BN, int EPI, int PT>
 __global__ __launch_bounds__((BM / (16 * PT)) * (BN >= 128 ? BN / 64 : 2) * 64) void k_conv_igemm_dma(
     const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ w, ConvGeom g, Epilogue ep) {
@@ -171,6 +177,13 @@ __global__ __launch_bounds__((BM / (16 * PT)) * (BN >= 128 ? BN / 64 : 2) * 64) 
     int q = slot;
     const int dmask = g.div - 1, dshift = g.div > 1 ? 1 : 0;   // div is 1 or 2
 
+    // Tensors below 4 GB (every layer of the SSD networks): LDS-DMA through buffer descriptors -- 32-bit byte offsets, a lane
+    // whose chunk is padding / out of range gets an offset beyond the buffer (the hardware writes zeros).  The 64-bit
+    // per-lane address form below it (global_load_lds) moves the same bytes 4-5 % slower (measured on the weight-gradient patch
+    // kernel, round 3) and remains for larger tensors.
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, g.dma32 ? (unsigned)g.B * g.H * g.W * g.C * 2u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, g.dma32 ? (unsigned)g.N * (unsigned)g.ldw * 2u : 0u, 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;
     auto issue_dma = [&](int buf) {
         const bool kvalid = q < g.nchunks;
 #pragma unroll
@@ -181,15 +194,23 @@ __global__ __launch_bounds__((BM / (16 * PT)) * (BN >= 128 ? BN / 64 : 2) * 64) 
             // unsigned compares fold the >= 0 tests; the element offset fits 32 bits (tensor < 4G elements, host check)
             const bool ok = kvalid && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W && (((ny | nx) & dmask) == 0);
             const unsigned off = (unsigned)(ibase[j] + iy * g.W + ix) * (unsigned)g.C + (unsigned)(cc * 8);
-            const bf16_raw* src = ok ? x + off : reinterpret_cast<const bf16_raw*>(g_zero16);
-            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(s_x(buf) + i * 1024), 16, 0, 0);
+            if (g.dma32) {
+                dma16_buf(xres, s_x(buf) + i * 1024, ok ? off * 2u : OOB);
+            } else {
+                const bf16_raw* src = ok ? x + off : reinterpret_cast<const bf16_raw*>(g_zero16);
+                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(s_x(buf) + i * 1024), 16, 0, 0);
+            }
         }
 #pragma unroll
         for (int j = 0; j < WI; ++j) {
             const int i = (wave & 1) + 2 * ((wave >> 1) + (NW / 2) * j);
-            const bf16_raw* src = (kvalid && wrow[j] != ~0u) ? w + (wrow[j] + (unsigned)(q * 8))
-                                                             : reinterpret_cast<const bf16_raw*>(g_zero16);
-            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(s_w(buf) + i * 1024), 16, 0, 0);
+            const bool wok = kvalid && wrow[j] != ~0u;
+            if (g.dma32) {
+                dma16_buf(wres, s_w(buf) + i * 1024, wok ? (wrow[j] + (unsigned)(q * 8)) * 2u : OOB);
+            } else {
+                const bf16_raw* src = wok ? w + (wrow[j] + (unsigned)(q * 8)) : reinterpret_cast<const bf16_raw*>(g_zero16);
+                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(s_w(buf) + i * 1024), 16, 0, 0);
+            }
         }
         q += 8;
         cc += 8;
@@ -1964,6 +1985,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_wgrad_patch(const bf16_raw* __r
     const int ntiles = g.B * tiles_x * tiles_y;
     const int t_begin = split * tiles_per_split, t_end = min(ntiles, t_begin + tiles_per_split);
 
+    // (buffer-descriptor DMA: 32-bit byte offsets, a lane outside the map / the tile gets an out-of-range offset and the
+    //  hardware writes zeros -- no 64-bit address arithmetic and no zero block)
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (unsigned)g.B * g.H * g.W * g.C * 2u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dyres = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (unsigned)g.B * g.Ho * g.Wo * g.N * 2u, 0x00020000);
+    constexpr unsigned WP_OOB = 0xfffffff0u;
     // DMA ownership: instruction i of the dY tile / of the patch goes to loader wave i % 4
     auto issue_dma = [&](int t, int buf) {
         int r = t;
@@ -1982,9 +2008,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_wgrad_patch(const bf16_raw* __r
             const int y = y0 + 2 * rp + ((kk >> 3) & 1), xx = x0 + xg * 8 + (kk & 7);
             const int co = co0 + c16 * 8;
             const bool ok = pg < G::NPG && y < g.Ho && xx < g.Wo && co < g.N;
-            const bf16_raw* src = ok ? dy + ((unsigned)((b * g.Ho + y) * g.Wo + xx) * (unsigned)g.N + (unsigned)co)
-                                     : reinterpret_cast<const bf16_raw*>(g_zero16);
-            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(base + i * 1024), 16, 0, 0);
+            const unsigned off = ((unsigned)((b * g.Ho + y) * g.Wo + xx) * (unsigned)g.N + (unsigned)co) * 2u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dyres, (lds_void*)(base + i * 1024), 16, ok ? off : WP_OOB, 0, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < (G::P_INSTR + 3) / 4; ++j) {
@@ -1995,9 +2020,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_wgrad_patch(const bf16_raw* __r
                 const int py = pp / G::PW, px = pp - py * G::PW;
                 const int iy = y0 - 1 + py, ix = x0 - 1 + px;
                 const bool ok = pp < G::PPIX && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
-                const bf16_raw* src = ok ? x + ((unsigned)((b * g.H + iy) * g.W + ix) * (unsigned)g.C + (unsigned)(ci0 + c16 * 8))
-                                         : reinterpret_cast<const bf16_raw*>(g_zero16);
-                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(base + G::DY_BYTES + i * 1024), 16, 0, 0);
+                const unsigned off = ((unsigned)((b * g.H + iy) * g.W + ix) * (unsigned)g.C + (unsigned)(ci0 + c16 * 8)) * 2u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)(base + G::DY_BYTES + i * 1024), 16, ok ? off : WP_OOB, 0, 0, 0);
             }
         }
     };
@@ -3159,7 +3183,8 @@ static int conv2d_bwd_weight_impl(const void* x, const void* dy, float* dw, floa
         launch_wgrad_reduce(s, slab_w, (long long)ldy * ktot, (long long)Cout * ktot, dw, slab_b, (long long)ldy, Cout, dbias, nsr);
         return ssd_launch_status();
     }
-    if (wgrad_use_patch(H, W, Ho, Wo, Cin, ksize, stride, pad_t, pad_l)) {
+    if (wgrad_use_patch(H, W, Ho, Wo, Cin, ksize, stride, pad_t, pad_l) &&
+        (long long)B * H * W * Cin * 2 < (1ll << 32) - 16 && (long long)B * Ho * Wo * ldy * 2 < (1ll << 32) - 16) {   // 32-bit DMA offsets
         int tx, ty, tps, ns;
         wgrad_patch_plan(B, Ho, Wo, Cin, Cout, &tx, &ty, &tps, &ns);
         float* slab_w = static_cast<float*>(ws);

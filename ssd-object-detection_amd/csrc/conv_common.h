@@ -53,6 +53,7 @@ struct ConvGeom {
     int cls_n[4];                            // pixels per class (B * cls_h[py] * cls_w[px]), class = 2*py + px
     int cls_h[2], cls_w[2];
     int ablate;                              // dev only (SSD_ABLATE): 1 no DMA after the prologue, 2 no wait/barrier, 4 no MFMA
+    int dma32;                               // source tensor and weights below 4 GB: LDS-DMA through buffer descriptors (32-bit byte offsets)
 };
 
 enum { EPI_FWD = 0, EPI_HEAD = 1, EPI_DGRAD = 2 };
@@ -632,6 +633,7 @@ inline ConvGeom make_geom(int B, int H, int W, int C, int Ho, int Wo, int N, int
 #else
     g.ablate = 0;
 #endif
+    g.dma32 = ((long long)B * H * W * C < (1ll << 31) - 16 && (long long)N * g.ldw < (1ll << 31) - 16) ? 1 : 0;
     g.s2 = 0;
     const int s2on = ssd_knob("SSD_DGRAD_S2", 1);
     if (div == 2 && s2on && g.cpt % 8 == 0) {

@@ -73,6 +73,11 @@ class SSDObjectDetectionModel:
         self._targets_event = None
         self._match_ws = ops.MatchWorkspace()
         self.fused_optimizer = os.environ.get("SSD_FUSED_OPTIMIZER", "1") == "1"   # Adam per bucket inside backward
+        # the step's main chain (forward, loss, data gradients) runs on a HIGH-priority stream: its kernels are the critical
+        # path, the weight gradients / optimizer on the engine's side stream fill in around them (measured: -0.04 ms per step;
+        # the other way round, side stream high, +0.13 ms)
+        self.high_priority_main = os.environ.get("SSD_MAIN_PRIO", "-1") == "-1"
+        self._main_hi = None
 
     # ------------------------------------------------------------------ accessors
     def get_prior_box(self):
@@ -194,8 +199,20 @@ class SSDObjectDetectionModel:
         return out[3], info
 
     # ------------------------------------------------------------------ train step (A7)
-    def _train_step(self, image, gt_cls, gt_bbox, gt_mask, ssd_optimizer, stage="train", set_names=None,
-                    set_colors=None, step=0, cfg=None):
+    def _train_step(self, *args, **kwargs):
+        if not self.high_priority_main or not torch.cuda.is_available():
+            return self._train_step_on_current(*args, **kwargs)
+        if self._main_hi is None:
+            self._main_hi = torch.cuda.Stream(priority=-1)
+        cur = torch.cuda.current_stream()
+        self._main_hi.wait_stream(cur)
+        with torch.cuda.stream(self._main_hi):
+            out = self._train_step_on_current(*args, **kwargs)
+        cur.wait_stream(self._main_hi)             # the caller's stream sees the step complete, as before
+        return out
+
+    def _train_step_on_current(self, image, gt_cls, gt_bbox, gt_mask, ssd_optimizer, stage="train", set_names=None,
+                               set_colors=None, step=0, cfg=None):
         eng = self._engine
         batch_size = image.shape[0]
         batch_step = batch_size if (cfg is None or not cfg.split_batch) else cfg.split_batch_size

@@ -49,7 +49,9 @@ class GradReducer:
         total = sum(self.blocks)
         self.buckets = make_buckets(self.blocks, max(1, (total + n_buckets - 1) // n_buckets))
         self.use_streams = flat_grad.is_cuda
-        self.comm = torch.cuda.Stream() if self.use_streams else None
+        # high priority: the collective's few workgroups must not queue behind compute kernels that fill every CU (the
+        # exchange of a bucket is what its optimizer step -- and the end of the step -- waits for)
+        self.comm = torch.cuda.Stream(priority=-1) if self.use_streams else None
         self.profile = False                  # True: events around every bucket's exchange (bucket_times_ms)
         self._events = []
         self.begin()

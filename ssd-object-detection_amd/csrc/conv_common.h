@@ -511,22 +511,25 @@ __device__ __forceinline__ void staged_store(char* smem, const ConvGeom& g, cons
                             cand[q] = make_uint4(0, 0, 0, 0);      // a position outside the map never wins: 0 only ties with 0 = dead
                             if (row_to_m(row) >= 0) cand[q] = lds_ld16_scoped(smem + row * (BN * 2) + (((ch ^ row) & (CPR - 1)) << 4), smem);
                         }
+                        // (the packed 16-bit instructions are written out: from vector-typed C++ the compiler turned every
+                        //  min(x, 1) into a compare + select per half -- 218 vector instructions per thread for this stage,
+                        //  a quarter of the MFMA time of a 64-channel block; ~18 per word now)
                         unsigned o4[4], cw = 0;
-                        const us2 one = {1, 1}, four = {4, 4};
+                        const unsigned one = 0x00010001u, four = 0x00040004u;
+                        auto pk_max = [](unsigned x, unsigned y) { unsigned r; asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+                        auto pk_min = [](unsigned x, unsigned y) { unsigned r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+                        auto pk_mad = [](unsigned x, unsigned y, unsigned z) { unsigned r; asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z)); return r; };
+                        auto pk_sub = [](unsigned x, unsigned y) { unsigned r; asm("v_pk_sub_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const unsigned w0 = (&cand[0].x)[k], w1 = (&cand[1].x)[k], w2 = (&cand[2].x)[k], w3 = (&cand[3].x)[k];
-                            const us2 a = __builtin_bit_cast(us2, w0), b2 = __builtin_bit_cast(us2, w1), c2 = __builtin_bit_cast(us2, w2),
-                                      d2 = __builtin_bit_cast(us2, w3);
-                            const us2 m = __builtin_elementwise_max(__builtin_elementwise_max(a, b2), __builtin_elementwise_max(c2, d2));
-                            const us2 ne0 = __builtin_elementwise_min((us2)(a ^ m), one), ne1 = __builtin_elementwise_min((us2)(b2 ^ m), one),
-                                      ne2 = __builtin_elementwise_min((us2)(c2 ^ m), one);
-                            const us2 t = ne1 * ne2 + ne1;                   // ne1 (1 + ne2)
-                            const us2 first = ne0 * t + ne0;                 // index of the first candidate equal to the max
-                            const us2 alive = __builtin_elementwise_min(m, one);
-                            const us2 code = alive * (us2)(first - four) + four;   // 4 = no winner (max is 0)
-                            o4[k] = __builtin_bit_cast(unsigned, m);
-                            const unsigned cu = __builtin_bit_cast(unsigned, code);
+                            const unsigned m = pk_max(pk_max(w0, w1), pk_max(w2, w3));
+                            const unsigned ne0 = pk_min(w0 ^ m, one), ne1 = pk_min(w1 ^ m, one), ne2 = pk_min(w2 ^ m, one);
+                            const unsigned t = pk_mad(ne1, ne2, ne1);            // ne1 (1 + ne2)
+                            const unsigned first = pk_mad(ne0, t, ne0);          // index of the first candidate equal to the max
+                            const unsigned alive = pk_min(m, one);
+                            const unsigned cu = pk_mad(alive, pk_sub(first, four), four);   // 4 = no winner (max is 0)
+                            o4[k] = m;
                             cw |= ((cu & 0xfu) | ((cu >> 12) & 0xf0u)) << (8 * k);
                         }
                         *reinterpret_cast<uint4*>(ep.pool_out + po * g.N + n) = make_uint4(o4[0], o4[1], o4[2], o4[3]);

@@ -115,6 +115,7 @@ class SSDEngine:
         self.tail_stream = os.environ.get("SSD_TAIL_STREAM", "1") == "1"
         self.big_heads_side = os.environ.get("SSD_BIG_HEADS_SIDE", "1") == "1"
         self.pack_side = os.environ.get("SSD_PACK_SIDE", "1") == "1"
+        self.opt_defer = int(os.environ.get("SSD_OPT_DEFER", "1"))       # fused-optimizer buckets run at the end of the main stream
         self.pool_only = {}                    # node -> whether a pool-only kernel serves it (learned at the first call)
         self.fuse_unpool = {} if os.environ.get("SSD_FUSE_UNPOOL", "1") == "1" else None    # node -> data gradient un-pools itself
         # activation index -> its sign bits are written by the forward kernel (learned at the first call); data-gradient
@@ -464,6 +465,13 @@ class SSDEngine:
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.overlap_heads else None
         opt_at = {}
+        deferred, defer_nodes = [], set()
+        if fused_adam is not None:
+            ndefer = self.opt_defer
+            trunk_nodes = [node for _, _, node in self.opt_buckets() if node is not None]
+            # the last bucket (lowest node) follows its own weight gradients on the side stream; the `ndefer` before it go to the
+            # END of the main stream, which finishes its chain ~0.3 ms before the side stream does
+            defer_nodes = set(trunk_nodes[max(0, len(trunk_nodes) - 1 - ndefer):len(trunk_nodes) - 1]) if ndefer > 0 else set()
         if fused_adam is not None:
             self.step_count += 1
             t = self.step_count
@@ -477,6 +485,11 @@ class SSDEngine:
                 on_dgrad(node)
             if node in opt_at:
                 t0, t1 = opt_at.pop(node)
+                if side is not None and node is not None and node in defer_nodes:
+                    ev = torch.cuda.Event()
+                    ev.record(side)                    # the bucket's weight gradients are all enqueued there by now
+                    deferred.append((t0, t1, ev))
+                    return
                 on_side(lambda ws: self.adam_range(t0, t1, lr_t, hp["beta1"], hp["beta2"], hp["eps"], hp["clip"]), [])
 
         def on_side(fn, tensors):
@@ -632,6 +645,9 @@ class SSDEngine:
             written[i] = True
             opt_bucket(i)
         assert not opt_at
+        for t0, t1, ev in deferred:
+            main.wait_event(ev)
+            self.adam_range(t0, t1, lr_t, hp["beta1"], hp["beta2"], hp["eps"], hp["clip"])
         if side is not None:
             main.wait_stream(side)
 

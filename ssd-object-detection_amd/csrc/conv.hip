@@ -727,6 +727,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
                     for (int c = 0; c < CT; ++c) fw[t][c] = ldf(wb + wbase + t * WBYTES + c * 1024);
                 }
+                __builtin_amdgcn_s_setprio(0);               // (as in the 128-channel form below)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     if (2 * st + t > 8) continue;
@@ -736,6 +737,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                         for (int p = 0; p < PT; ++p)
                             acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[t][c], fx[t][p], acc[c][p], 0, 0, 0);
                 }
+                __builtin_amdgcn_s_setprio(3);
             }
         }
     } else {
@@ -765,11 +767,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int p = 0; p < PT; ++p) fx[p] = ldf(tapoff + p * prow);
 #pragma unroll
             for (int c = 0; c < CT; ++c) fw[c] = ldf(wb + wbase + c * 1024);
+            // the MFMA block runs at LOW priority, everything else of a step (wait, barrier, DMA issue, fragment reads) at high:
+            // the short instructions of one workgroup's step slip in between the MFMAs of the other's (+3 % on every layer)
+            __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int c = 0; c < CT; ++c)
 #pragma unroll
                 for (int p = 0; p < PT; ++p)
                     acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[c], fx[p], acc[c][p], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(3);
         }
     }
     }
@@ -1198,6 +1204,7 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
         else if (prev_st == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
+        __builtin_amdgcn_s_setprio(0);
         int r = t;
         const int tx = r % tiles_x; r /= tiles_x;
         const int ty = r % tiles_y;
@@ -1269,6 +1276,11 @@ void k_conv3x3_c64b(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__
             }
             __builtin_amdgcn_sched_barrier(0);              // keep the reads FD - 1 steps ahead, no further (144 VGPRs of weights)
         }
+        // From here to the barrier at the top of the next block this wave runs at high priority: its epilogue (conversions, LDS
+        // turn, stores / the fused weight gradient) is a few hundred short instructions that were being starved of issue slots
+        // by the OTHER workgroup's stream of 144 MFMAs on the same SIMD -- the two workgroups of a CU did not overlap, they took
+        // turns (section 4: "the second workgroup hides only half").  W0 form 480 -> 446 us, forward 410 -> 403 us.
+        __builtin_amdgcn_s_setprio(3);
         if (g.ablate & 8) {
 #pragma unroll
             for (int c = 0; c < 2; ++c)

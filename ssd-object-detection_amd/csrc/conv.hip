@@ -2140,6 +2140,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_wgrad_patch(const bf16_raw* __r
             };
             static_assert(G::KS == 8, "the hand-unrolled pipeline below assumes eight k-steps per block");
             load_frag(f0, ab, gb, std::integral_constant<int, 0>{});
+            // the woven fragment-read / MFMA stream of a block runs at LOW priority, the top of the block (wait, barrier, the
+            // loaders' DMA issue, address set-up, first fragments) at high: the two waves of a SIMD are in different phases for
+            // most of a block (loader / partner), and the one in its MFMAs no longer holds the other one up: +3-5 % per layer
+            __builtin_amdgcn_s_setprio(0);
             load_frag(f1, ab, gb, std::integral_constant<int, 1>{}); mma(f0); weave();
             load_frag(f0, ab, gb, std::integral_constant<int, 2>{}); mma(f1); weave();
             load_frag(f1, ab, gb, std::integral_constant<int, 3>{}); mma(f0); weave();
@@ -2148,6 +2152,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wgrad_patch(const bf16_raw* __r
             load_frag(f0, ab, gb, std::integral_constant<int, 6>{}); mma(f1); weave();
             load_frag(f1, ab, gb, std::integral_constant<int, 7>{}); mma(f0); weave();
             mma(f1);
+            __builtin_amdgcn_s_setprio(3);
         }
     };
     if (role == 0) run(std::integral_constant<int, 0>{}, std::false_type{});

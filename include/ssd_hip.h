@@ -137,7 +137,8 @@ int ssd_iou_n(const float* b1, const double* b2, int n, double* out, void* strea
  *   grad_scale multiplies both gradients (1.0 = d total_loss)
  *   out8      float[8]: loc loss, cls loss pos, cls loss neg (the reference's three scalars, :392-394),
  *             their sum, P, N (= number of mined negatives, ties included :372), tau, status
- *             (0 ok; 1 = P==0 or 3P > B*A, where TF would raise; 2 = tau==0, where the assert at :375 fires)
+ *             (0 ok; 1 = P==0 or 3P > B*A, where TF would raise; 2 = tau==0, where the assert at :375 fires;
+ *             3 = a logit row or a positive's offsets were NaN / Inf: a diverged run, reported first)
  *   dconf     [B*A*C], dloc [B*A*4]: gradients, same dtype as conf/loc
  * Hard-negative mining is global over the B images handed in (one micro-batch), as in the reference.
  * fp32 losses agree with a float64 evaluation to <= 1e-4 relative.

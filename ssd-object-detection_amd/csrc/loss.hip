@@ -40,7 +40,7 @@ struct LossWs {                              // layout of the caller's workspace
     int* hist1s;                             // [H1STRIDE] replicas collapsed (by k_loss_hist<2>)
     int* hist2;
     int* hist3;
-    int* counters;                           // [4..7] = select result {tau_bits, n_neg lo, n_neg hi, ok}; [3] = P
+    int* counters;                           // [4..7] = select result {tau_bits, n_neg lo, n_neg hi, ok}; [3] = P; [2] = a logit / offset was not finite
     double* part_pos;                        // [nblk] per-block sum of positive CE
     double* part_l1;                         // [nblk] per-block sum of |pred-gt| over positives
     double* part_neg;                        // [nblk] per-block sum of selected background CE
@@ -104,6 +104,7 @@ __global__ __launch_bounds__(WG) void k_loss_rows(const T* __restrict__ conf, co
     const size_t nblk = (n + ROWS - 1) / ROWS;
     for (int i = threadIdx.x; i < HB1; i += WG) s_hist[i] = 0;
     int my_pos = 0;
+    bool not_finite = false;                  // NaN / Inf in a logit row or in a positive's offsets (status 3)
     const int r = threadIdx.x >> 1, half = threadIdx.x & 1;
     const int k0 = half ? (C + 1) / 2 : 0, k1 = half ? C : (C + 1) / 2;
     constexpr int FIXED = (CC + 1) / 2;                       // trip count of the longer half row
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(WG) void k_loss_rows(const T* __restrict__ conf, co
                 const size_t g = row0 + r;
                 const float logs = __logf(s);
                 const float lse = m + logs;
+                not_finite |= !(fabsf(lse) < INFINITY);
                 const bool is_pos = mask[g] != 0;
                 const float ce_bg = is_pos ? 0.f : (m - z[C - 1]) + logs;      // >= 0 by construction
                 w.ce_bg[g] = ce_bg;
@@ -165,6 +167,7 @@ __global__ __launch_bounds__(WG) void k_loss_rows(const T* __restrict__ conf, co
                     const T* pl = loc + 4 * g;
                     acc_l1 = (double)(fabsf(to_f32<T>(pl[0]) - gl.x) + fabsf(to_f32<T>(pl[1]) - gl.y) +
                                       fabsf(to_f32<T>(pl[2]) - gl.z) + fabsf(to_f32<T>(pl[3]) - gl.w));
+                    not_finite |= !(acc_l1 < (double)INFINITY);
                 }
             }
         }
@@ -181,6 +184,7 @@ __global__ __launch_bounds__(WG) void k_loss_rows(const T* __restrict__ conf, co
     for (int i = threadIdx.x; i < HB1; i += WG)
         if (s_hist[i]) atomicAdd(&rep[i], s_hist[i]);
     if (threadIdx.x == 0 && s_np) atomicAdd(&rep[HB1], s_np);
+    if (__any(not_finite) && (threadIdx.x & 63) == 0) atomicOr(&w.counters[2], 1);
 }
 
 // Find, in a histogram of `nb` bins scanned from the top, the bin holding the k-th largest key.
@@ -405,7 +409,9 @@ __global__ __launch_bounds__(WG) void k_loss_grad(const T* __restrict__ conf, co
 
 // Final: fixed-order reduction of the per-block partial sums -> the reference's three loss scalars.
 // out[0..7] = loc, cls-pos, cls-neg, total, P, N, tau, status (0 ok; 1 = P==0 / k>n (TF top_k would
-// raise); 2 = tau==0, i.e. the reference's assert at models/ssd_model.py:375 would fire)
+// raise); 2 = tau==0, i.e. the reference's assert at models/ssd_model.py:375 would fire; 3 = a logit row or a positive's
+// offsets were not finite -- the reference would log NaN losses from there on; takes precedence: a diverged run must not
+// look like an empty batch)
 __global__ __launch_bounds__(WG) void k_loss_final(size_t nblk, LossWs w, float* __restrict__ out) {
     __shared__ double s_red[4];
     const Select sel = load_select(w);
@@ -421,7 +427,8 @@ __global__ __launch_bounds__(WG) void k_loss_final(size_t nblk, LossWs w, float*
         const float l_neg = sel.ok && sel.n_neg > 0 ? (float)(c / (double)sel.n_neg) : 0.f;
         out[0] = l_loc; out[1] = l_pos; out[2] = l_neg; out[3] = l_loc + l_pos + l_neg;
         out[4] = (float)P; out[5] = (float)sel.n_neg; out[6] = __uint_as_float(sel.tau_bits);
-        out[7] = !sel.ok ? 1.f : (sel.tau_bits == 0 ? 2.f : 0.f);
+        const bool bad = w.counters[2] != 0 || !(fabs(a) < (double)INFINITY) || !(fabs(b) < (double)INFINITY) || !(fabs(c) < (double)INFINITY);
+        out[7] = bad ? 3.f : (!sel.ok ? 1.f : (sel.tau_bits == 0 ? 2.f : 0.f));
     }
 }
 

@@ -63,7 +63,8 @@ __device__ __forceinline__ void stage_load(const T* __restrict__ src, size_t cou
     constexpr int PER = 16 / sizeof(T);
     const size_t nvec = count / PER;
     const uint4* v = reinterpret_cast<const uint4*>(src);
-    const size_t last = nvec ? nvec - 1 : 0;
+    if (nvec == 0) return;                      // fewer elements than one 16-byte chunk: stage_store takes them one by one
+    const size_t last = nvec - 1;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const size_t i = (size_t)j * RB_WG + threadIdx.x;

@@ -90,14 +90,14 @@ class FusedView:
 
 class SSDEngine:
     def __init__(self, classes=81, in_size=300, trunk=SSD300_TRUNK, num_priors=SSD300_NUM_PRIORS, device="cuda",
-                 seed=0):
+                 seed=0, sparse_heads=None):
         self.L = _lib.lib()
         self.classes, self.in_size, self.device = classes, in_size, torch.device(device)
         self.trunk, self.num_priors = list(trunk), tuple(num_priors)
         self.block = self.L.ssd_opt_block_elems()
         # the heads' backward pass from the loss's compact gradient rows (csrc/sparse.hip); SSD_SPARSE_HEADS=0: the dense
         # kernels on the scattered gradient (tests compare the two)
-        self.sparse_heads = os.environ.get("SSD_SPARSE_HEADS", "1") == "1"
+        self.sparse_heads = (os.environ.get("SSD_SPARSE_HEADS", "1") == "1") if sparse_heads is None else bool(sparse_heads)
         self._plan_shapes()
         self._plan_params()
         self._alloc_params()
@@ -125,6 +125,7 @@ class SSDEngine:
         # second layer's data gradient and first layer's weight gradient in one kernel (the gradient w.r.t. the first layer's
         # output has no other consumer and is never stored); False after a refusal
         self.fuse_first = os.environ.get("SSD_FUSE_FIRST", "1") == "1"
+        self.wgrad_probe = None                # dict(nodes={...}, events=[]): time those layers' weight-gradient launches in the step
 
     # ---------------------------------------------------------------- static planning
     def _plan_shapes(self):
@@ -600,9 +601,18 @@ class SSDEngine:
                 on_side(lambda ws: None, [wt.index, bt.index])
                 opt_bucket(i)
                 continue
-            on_side(lambda ws, a=acts[i], go=g_out, nd=nd, wt=wt, bt=bt: ops.conv2d_bwd_weight(
-                a, go, nd["cout"], nd["k"], nd["stride"], nd["pt"], nd["pl"], dw=self.view(wt, self.grad),
-                dbias=self.view(bt, self.grad), ws=ws), [wt.index, bt.index])
+            def wgrad(ws, i=i, a=acts[i], go=g_out, nd=nd, wt=wt, bt=bt):
+                probe = self.wgrad_probe          # measurement only (bench.py): HIP events around the launches of chosen layers
+                timed = probe is not None and i in probe["nodes"]
+                if timed:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                ops.conv2d_bwd_weight(a, go, nd["cout"], nd["k"], nd["stride"], nd["pt"], nd["pl"], dw=self.view(wt, self.grad),
+                                      dbias=self.view(bt, self.grad), ws=ws)
+                if timed:
+                    e1.record()
+                    probe["events"].append((i, e0, e1))
+            on_side(wgrad, [wt.index, bt.index])
             if i == 0:
                 opt_bucket(i)
                 continue                          # no gradient w.r.t. the image

@@ -56,10 +56,14 @@ def _init_distributed():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1:
         return 0, 1
-    # RCCL needs one GPU per rank; with fewer GPUs than ranks (a one-GPU box rehearsing the multi-rank path) ranks share a
-    # device and the exchange goes over gloo (the rule of bench.py)
+    # RCCL needs one GPU per rank ON THIS NODE; with fewer GPUs than local ranks (a one-GPU box rehearsing the multi-rank
+    # path) ranks share a device and the exchange goes over gloo.  The count that matters is the node's rank count
+    # (LOCAL_WORLD_SIZE, set by torch.distributed.run), not the job's: 2 nodes x 8 GPUs is 16 ranks on 8 devices each.
     n_dev = torch.cuda.device_count()
-    backend = os.environ.get("SSD_DIST_BACKEND", "nccl" if n_dev >= world else "gloo")
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    backend = os.environ.get("SSD_DIST_BACKEND", "nccl" if n_dev >= local_world else "gloo")
+    logger.info("distributed backend %s (%d ranks, %d on this node, %d devices)", backend, world,
+                                     local_world, n_dev)
     if torch.cuda.is_available():
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % n_dev)
     if not torch.distributed.is_initialized():

@@ -26,6 +26,12 @@ class NoPositivesError(ValueError):
     reference's tf.math.top_k / division would raise at that step (models/ssd_model.py:359,368)."""
 
 
+class NonFiniteLossError(FloatingPointError):
+    """status == 3 in a logged row: a logit row or a positive's predicted offsets were NaN / Inf -- the run has diverged
+    (the reference would go on logging NaN losses; the convolution epilogues here are compiled without NaN semantics, so
+    the loss kernel is where a diverged run is caught)."""
+
+
 class ScalarLog:
     def __init__(self, log_dir, device, capacity=512, distributed=False, console_interval=10, logger=None):
         self.path = os.path.join(log_dir, "scalars.jsonl")
@@ -85,6 +91,8 @@ class ScalarLog:
         bad = [(m, int(r[7])) for m, r in zip(rows, host) if r[7] != 0]
         if bad:
             (stage, step, _), status = bad[0]
+            if status == 3:
+                raise NonFiniteLossError("non-finite logits / offsets at %s step %d: the run has diverged" % (stage, step))
             if status == 2:
                 raise HardNegativeThresholdError("hard-negative threshold reached 0 at %s step %d "
                                                  "(reference assert, models/ssd_model.py:375)" % (stage, step))

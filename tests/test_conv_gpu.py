@@ -287,6 +287,32 @@ def test_p512_row_strip_full_size_vs_fp32_oracle(ops):
     assert (acc - want).abs().max().item() <= 2 ** -6 * max(1.0, want.abs().max().item())
 
 
+def test_wgrad_patch_full_size_vs_fp32_oracle(ops):
+    """The step's dominant kernel at a size it runs at -- k_conv3x3_wgrad_patch<16,2> on block3_conv2/3's shape at batch 64
+    (75 x 75 x 256 -> 256: 16 channel tiles x 16 pixel splits over the 256 workgroups, ragged 16x16 blocks on the right and
+    bottom edges, XCD groups, the split reduction) -- directly against the fp32 reference (torch CPU autograd), same 1e-3 bound
+    as the small cases, bias gradient too, and bitwise reproducible.  The other five launches of a step differ in channel
+    counts only (64 ... 256: the same code with fewer tiles and more splits, covered at (8,48,48,64,128))."""
+    from ssd_object_detection_amd import _lib
+    from tests.conv_cases import plan_name
+    B, H, W, Cin, Cout = 64, 75, 75, 256, 256
+    L = _lib.lib()
+    assert plan_name(L, L.ssd_conv2d_bwd_weight_plan(B, H, W, Cin, Cout, Cout, 3, 1, 1, 1, H, W)).startswith("k_conv3x3_wgrad_patch<16,2>")
+    g = torch.Generator().manual_seed(7575)
+    x = torch.randn((B, H, W, Cin), generator=g).relu().bfloat16()           # post-ReLU activations, as in the network
+    dy = torch.randn((B, H, W, Cout), generator=g).bfloat16()
+    xd, dyd = x.cuda(), dy.cuda()
+    dw, db = ops.conv2d_bwd_weight(xd, dyd, Cout, 3, 1, 1, 1)
+    dw2, db2 = ops.conv2d_bwd_weight(xd, dyd, Cout, 3, 1, 1, 1)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    w = torch.zeros((Cout, 3, 3, Cin), requires_grad=True)
+    ref_conv(x.float(), w, None, 3, 1, 1, 1, H, W, False).backward(dy.float())
+    assert (dw.cpu() - w.grad).abs().max().item() <= 1e-3 * max(1.0, w.grad.abs().max().item())
+    dbr = dy.float().sum((0, 1, 2))
+    assert (db.cpu() - dbr).abs().max().item() <= 1e-3 * max(1.0, dbr.abs().max().item())
+
+
 @pytest.mark.parametrize("shape", [0, 1, 2])
 def test_wgrad_patch_block_shapes(ops, shape):
     """Every block shape of the LDS-patch weight-gradient kernel (16x16, 6x40, 10x24) gives the same gradient;

@@ -233,3 +233,111 @@ def test_full_batch_is_image_independent(engine):
     assert torch.equal(g1_p, g1[perm])                       # gradient w.r.t. block1_conv1's output, per image
     err = float((grad_p - grad).norm() / grad.norm())
     assert err < 1e-3, err                                   # the same products summed in another order
+
+
+def test_dense_head_backward_matches_the_sparse_path():
+    """engine.backward's dense head branch (sparse_heads=False: gradient packing, head data / weight gradients on the dense
+    kernels, the large levels on the side stream with event-ordered accumulation) against the shipped sparse-row branch on the
+    same loss gradient: the head gradients come from the same products in another order (1e-3), the trunk gradients differ by
+    one bf16 rounding of each feature-map gradient.  Keeps the 70 lines of the fallback schedule from rotting untested."""
+    import ssd_object_detection_amd.ops as ops
+    from ssd_object_detection_amd.engine import SSDEngine
+    from ssd_object_detection_amd.data_loaders.synthetic import synth_batch_gt
+    B = 4
+    sparse = SSDEngine(classes=81, seed=5, sparse_heads=True)
+    dense = SSDEngine(classes=81, seed=5, sparse_heads=False)
+    assert sparse.sparse_heads and not dense.sparse_heads and torch.equal(sparse.param, dense.param)
+    g = torch.Generator().manual_seed(23)
+    x = ops.image_prep(torch.rand((B, 300, 300, 3), generator=g).cuda())
+    pset = ops.build_priors()
+    cls_l, box_l = synth_batch_gt(300, B)
+    targets = ops.match_encode(*ops.pack_gt(box_l, cls_l), pset, 0.5)
+    loc_s, conf_s = sparse.forward(x)
+    loc_d, conf_d = dense.forward(x)
+    assert torch.equal(loc_s, loc_d) and torch.equal(conf_s, conf_d)
+    out, dconf, dloc = ops.ssd_loss(conf_d, loc_d, *targets, grad_scale=64.0)
+    hgb = sparse.head_grad_buffers(B)
+    out_s = ops.ssd_loss_heads(conf_s, loc_s, *targets, hgb, grad_scale=64.0)
+    assert torch.equal(out, out_s)
+    assert dense.head_grad_buffers(B) is None
+    dense.backward(dloc, dconf)
+    sparse.backward(None, None, heads=hgb)
+    torch.cuda.synchronize()
+    gs, gd = sparse.grad.cpu(), dense.grad.cpu()
+    for t in gemm_arrays(sparse):
+        a, b = gs[t.offset:t.offset + t.numel], gd[t.offset:t.offset + t.numel]
+        err = rel_l2(a, b)
+        assert err < (2e-3 if t.name.startswith("head") else 2e-2), (t.name, err)
+    # the feature-map gradients the two paths hand to the trunk: one bf16 rounding apart
+    for ni, _, _ in sparse.fm:
+        a = sparse._acts(B)["gacts"][ni + 1].float()
+        b = dense._acts(B)["gacts"][ni + 1].float()
+        assert (a - b).abs().max() <= 2.0 ** -6 * b.abs().max() + 1e-12, ni
+
+
+def test_train_step_at_batch_64():
+    """BASELINE configs[2] itself, with assertions (the bench's loss_check asserts nothing): one full `_train_step` at batch
+    64 on the shipped path (sparse head rows, fused first-layer pair, per-bucket clip + Adam inside the backward pass, three
+    streams), then
+      * the compact gradient rows the step's loss wrote, scattered back, equal the dense-gradient form of the loss on the
+        step's own logits BIT FOR BIT, and so do the loss scalars;
+      * the loss scalars agree with the float64 oracle (models/ssd_model.py:341-396 restated) on those logits to 1e-4;
+      * weights, both Adam moments, bf16 and transposed copies equal those of the unfused sequence (backward, clip_scales,
+        adam on the whole flat buffer, targets assigned up front) bit for bit."""
+    from oracle import ssd_oracle as O
+    from ssd_object_detection_amd import ops, optimizers
+    from ssd_object_detection_amd.data_loaders.synthetic import synth_batch_gt
+    from ssd_object_detection_amd.models import SSDObjectDetectionModel
+    B = 64
+    gen = torch.Generator(device="cuda").manual_seed(64)
+    img = torch.rand((B, 300, 300, 3), generator=gen, device="cuda")
+    cls_l, box_l = synth_batch_gt(6400, B)
+    gt = ops.pack_gt(box_l, cls_l)
+
+    def run(fused):
+        model = SSDObjectDetectionModel(classes=80, log_dir="gpurun_out/t64", timestamp_dir=False, seed=2)
+        model.fused_optimizer = fused
+        opt = optimizers.Adam(1e-3)
+        x = ops.image_prep(img, normalize=True)
+        if fused:
+            tgt = model.match_async(gt)
+        else:
+            tgt = ops.match_encode(*gt, model._pset, 0.5)
+        conf, loc, info = model._train_step(x, *tgt, opt)
+        torch.cuda.synchronize()
+        return model, tgt, conf, loc, info
+
+    m1, tgt, conf, loc, info = run(True)
+    eng = m1.get_engine()
+    assert eng.sparse_heads and eng.fuse_first and float(info["status"]) == 0.0
+    # rows == dense gradient, scalars equal
+    hgb = eng.head_grad_buffers(B)
+    out_d, dconf, dloc = ops.ssd_loss(conf, loc, *tgt)
+    sl, sc = hgb.dense(81)
+    assert torch.equal(sl.view(torch.int16), dloc.view(torch.int16))
+    assert torch.equal(sc.view(torch.int16), dconf.view(torch.int16))
+    raw = m1._last_raw
+    assert torch.equal(raw, out_d)
+    P = int(tgt[2].sum())
+    assert int(raw[4]) == P and int(raw[5]) >= 3 * P
+    assert sum(hgb.count.cpu().tolist()[:6]) <= P + int(raw[5])
+    # float64 oracle on the step's own logits
+    ref = O.ssd_loss(tgt[0].cpu().numpy(), tgt[1].cpu().numpy(), tgt[2].cpu().numpy(), loc.float().cpu().numpy(),
+                     conf.float().cpu().numpy())
+    for key, want in (("loc loss", ref["loc"]), ("cls loss pos", ref["pos"]), ("cls loss neg", ref["neg"])):
+        got = float(info[key])
+        assert abs(got - want) <= 1e-4 * abs(want), (key, got, want)
+    assert ref["num_pos"] == P
+    # fused per-bucket optimizer == the unfused sequence
+    m2, _, conf2, loc2, info2 = run(False)
+    assert torch.equal(conf, conf2) and torch.equal(loc, loc2)
+    a, b = eng, m2.get_engine()
+    assert a.step_count == b.step_count == 1
+    for name in ("grad", "param", "adam_m", "adam_v", "param_bf16", "clip_scale", "grad_norms"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    for i in a.w_t:
+        assert torch.equal(a.w_t[i], b.w_t[i]), i
+    for u, v in zip(a.head_w_t, b.head_w_t):
+        assert torch.equal(u, v)
+    delta = (a.param - SSDObjectDetectionModel(classes=80, log_dir="gpurun_out/t64", timestamp_dir=False, seed=2).get_engine().param)
+    assert 0 < float(delta.abs().max()) < 2e-3                    # Adam's first step: ~lr per touched weight

@@ -108,6 +108,32 @@ def test_loss_status_codes(ops):
     assert out.cpu().numpy()[7] == 2.0                        # reference assert at models/ssd_model.py:375
 
 
+@pytest.mark.parametrize("where", ["logit_nan", "logit_inf", "offset_nan"])
+def test_loss_flags_non_finite_inputs(ops, where):
+    """status 3: the convolution epilogues are compiled without NaN semantics (ReLU may turn a NaN into 0), so the loss kernel is
+    where a diverged run must show: one NaN / Inf logit anywhere, or a non-finite predicted offset of a positive, sets status 3
+    in both forms of the loss (dense gradient and compact rows); clean inputs of the same shape give 0."""
+    B, A, C = 2, 8732, 81
+    cls, gloc, mask = make_targets(ops, B, first=17)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    conf = torch.randn((B, A, C), generator=g, device="cuda").bfloat16()
+    loc = (0.5 * torch.randn((B, A, 4), generator=g, device="cuda")).bfloat16()
+    hw, npc = (1444, 361, 100, 25, 9, 1), (4, 6, 6, 6, 4, 4)
+    npad = tuple((n * 85 + 7) // 8 * 8 for n in npc)
+    hgb = ops.HeadGradBuffers(B, hw, npc, npad)
+    assert float(ops.ssd_loss(conf, loc, cls, gloc, mask)[0][7]) == 0.0
+    assert float(ops.ssd_loss_heads(conf, loc, cls, gloc, mask, hgb)[7]) == 0.0
+    if where == "logit_nan":
+        conf[1, 5000, 17] = float("nan")            # a background anchor somewhere in the middle
+    elif where == "logit_inf":
+        conf[0, 8731, 80] = float("inf")
+    else:
+        pos = mask[1].nonzero()[0, 0]
+        loc[1, pos, 2] = float("nan")
+    assert float(ops.ssd_loss(conf, loc, cls, gloc, mask)[0][7]) == 3.0
+    assert float(ops.ssd_loss_heads(conf, loc, cls, gloc, mask, hgb)[7]) == 3.0
+
+
 def test_loss_full_config_properties(ops):
     """BASELINE config 2 size (B=32, bf16): size-independent properties of the gradient."""
     B, A, C = 32, 8732, 81

@@ -92,6 +92,17 @@ def test_status_1_is_an_error_too(tmp_path):
     log.close()
 
 
+def test_status_3_non_finite_logits(tmp_path):
+    """status 3 (a NaN / Inf logit row or offset reached the loss kernel): its own exception type, and it outranks the others."""
+    log = SL.ScalarLog(str(tmp_path), "cpu", capacity=8)
+    log.record("train", 1, row(1, 1, 1), 1e-3)
+    log.record("train", 2, row(float("nan"), 1, 1, status=3.0), 1e-3)
+    with pytest.raises(SL.NonFiniteLossError, match="step 2"):
+        log.flush()
+    assert issubclass(SL.NonFiniteLossError, FloatingPointError)
+    log.close()
+
+
 def test_close_without_collective_does_not_touch_the_process_group(tmp_path, monkeypatch):
     """Unwinding from an exception on one rank: close(collective=False) must write local rows without an all-reduce."""
     log = SL.ScalarLog(str(tmp_path), "cpu", capacity=8, distributed=True)

@@ -370,7 +370,7 @@ enum ssd_conv_plan {
     SSD_PLAN_KERNEL_MASK = 0xff,
     SSD_PLAN_C64B = 1, SSD_PLAN_P32_64, SSD_PLAN_P32_128, SSD_PLAN_8PH,
     SSD_PLAN_DMA_256_256, SSD_PLAN_DMA_256_128, SSD_PLAN_DMA_256_64, SSD_PLAN_DMA_128_64, SSD_PLAN_DMA_128_128,
-    SSD_PLAN_CONV0_FWD, SSD_PLAN_P512,
+    SSD_PLAN_CONV0_FWD, SSD_PLAN_P512, SSD_PLAN_PW,
     SSD_PLAN_WG_FIRST = 32, SSD_PLAN_WG_PATCH_16x16, SSD_PLAN_WG_PATCH_6x40, SSD_PLAN_WG_PATCH_10x24, SSD_PLAN_WG_TILE,
     SSD_PLAN_WG_GENERIC,
     SSD_PLAN_F_FLAT = 0x100,         /* strip blocks over a narrow map */

@@ -17,3 +17,9 @@ static inline size_t ssd_align_up(size_t x, size_t a) { return (x + a - 1) / a *
 
 // Development overrides (ssd_dev_knob, include/ssd_hip.h); defined in conv.hip.  Never set by the product.
 int ssd_knob(const char* name, int dflt);
+
+// Persistent pointwise-convolution GEMM (pwgemm.hip), called from conv.hip's dispatch.  geom / epilogue: the ConvGeom / Epilogue
+// of conv_common.h (both translation units include that header).
+bool ssd_pw_gemm_serves(int epi, const void* geom, const void* epilogue);
+int ssd_pw_gemm_launch(int epi, const void* x, const void* w, const void* geom, const void* epilogue, void* ws, size_t ws_bytes,
+                       void* stream);

@@ -2659,7 +2659,7 @@ Knob g_knobs[] = {{"SSD_ABLATE", {KNOB_UNSET}}, {"SSD_DGRAD_S2", {KNOB_UNSET}},
                   {"SSD_CONV_PATCH_FLAT", {KNOB_UNSET}}, {"SSD_WGRAD_FIRST", {KNOB_UNSET}}, {"SSD_CONV_FIRST", {KNOB_UNSET}},
                   {"SSD_WGRAD_PATCH_XCD", {KNOB_UNSET}}, {"SSD_CONV_C64", {KNOB_UNSET}}, {"SSD_CONV_POOL_FUSE", {KNOB_UNSET}},
                   {"SSD_CONV_PATCH_ROWFLAT", {KNOB_UNSET}}, {"SSD_MATCH_FUSED", {KNOB_UNSET}}, {"SSD_CONV_P512", {KNOB_UNSET}},
-                  {"SSD_C64B_WGS", {KNOB_UNSET}}};
+                  {"SSD_C64B_WGS", {KNOB_UNSET}}, {"SSD_CONV_PW", {KNOB_UNSET}}, {"SSD_PW_WGS", {KNOB_UNSET}}, {"SSD_PW_DYNAMIC", {KNOB_UNSET}}};
 Knob* find_knob(const char* name) {
     for (Knob& k : g_knobs) if (!strcmp(k.name, name)) return &k;
     return nullptr;
@@ -2779,6 +2779,14 @@ int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Epilogue
     }
     if (EPI == EPI_FWD && !ep.out) return SSD_ERR_VALUE;         // pool-only needs a pooling kernel
     if (ep.up_out) return SSD_ERR_UNSUPPORTED;                   // only the LDS-patch kernels un-pool in their epilogue
+    if constexpr (EPI != EPI_HEAD) {
+        // 1x1 / stride 1 on a large map: the persistent GEMM (pwgemm.hip) -- the DMA stream runs on across tile boundaries
+        // (SSD_CONV_PW: bit 0 forward, bit 1 data gradient)
+        if ((knob("SSD_CONV_PW", 3) & (EPI == EPI_FWD ? 1 : 2)) && !(g.ablate & 8) && ssd_pw_gemm_serves(EPI, &g, &ep)) {
+            SSD_PLAN(SSD_PLAN_PW);
+            return ssd_pw_gemm_launch(EPI, x, w, &g, &ep, ws, ws_bytes, s);
+        }
+    }
     {
         // tile choice: the CU ingests ~28 B/clk from L2, so MACs per staged byte decide the ceiling: prefer the
         // largest tile that still gives every CU work (>= ~2 workgroups per CU), SSD_CONV_TILE overrides (testing)
@@ -3338,6 +3346,7 @@ const char* ssd_conv_plan_name(int plan) {
         case SSD_PLAN_P32_128: return "k_conv3x3_patch32<128>";
         case SSD_PLAN_P512: return "k_conv3x3_p512";
         case SSD_PLAN_8PH: return "k_conv_igemm_8ph";
+        case SSD_PLAN_PW: return "k_pw_gemm";
         case SSD_PLAN_DMA_256_256: return "k_conv_igemm_dma<256,256>";
         case SSD_PLAN_DMA_256_128: return "k_conv_igemm_dma<256,128>";
         case SSD_PLAN_DMA_256_64: return "k_conv_igemm_dma<256,64>";

@@ -73,10 +73,11 @@ CASES = [
 
 # Shapes that reach the large-problem kernels; the first five and the last four are layers of the batch-64 SSD300 step.
 FULL_SIZE_CASES = [
-    (64, 38, 38, 512, 512, 1, 1, "same", ("k_conv_igemm_8ph", "k_conv_igemm_8ph", "k_conv_wgrad_tile+rwide")),          # conv12 (1x1 at 38x38)
-    (64, 19, 19, 1024, 1024, 1, 1, "same", ("k_conv_igemm_8ph", "k_conv_igemm_8ph", "k_conv_wgrad_tile")),              # conv14 (1x1 at 19x19)
+    (64, 38, 38, 512, 512, 1, 1, "same", ("k_pw_gemm", "k_pw_gemm", "k_conv_wgrad_tile+rwide")),                        # conv12 (1x1 at 38x38): the persistent pointwise GEMM
+    (64, 19, 19, 1024, 1024, 1, 1, "same", ("k_pw_gemm", "k_pw_gemm", "k_conv_wgrad_tile")),                            # conv14 (1x1 at 19x19)
     (64, 38, 38, 512, 1024, 3, 2, "same", ("k_conv_igemm_8ph", DMA % "256,256" + "+s2", "k_conv_wgrad_tile")),          # conv13 (3x3 stride 2, 38 -> 19)
-    (64, 19, 19, 1024, 256, 1, 1, "same", (DMA % "128,128", "k_conv_igemm_8ph", "k_conv_wgrad_tile+rwide")),            # conv15
+    (64, 19, 19, 1024, 256, 1, 1, "same", (DMA % "128,128", "k_pw_gemm", "k_conv_wgrad_tile+rwide")),                   # conv15 (91 tiles of 256x256 forward: the generic kernel; four k-tiles per tile backward)
+    (70, 19, 19, 320, 320, 1, 1, "same", ("k_pw_gemm", "k_pw_gemm", "k_conv_wgrad_tile+rwide")),                              # pointwise GEMM with a ragged last pixel tile (M = 25270) and a ragged channel tile (320 = 256 + 64)
     (64, 38, 38, 512, 340, 3, 1, "same", (P512 + "+flat", "k_conv_igemm_8ph", WP6)),                                    # head 0 (data gradient from 344 padded channels)
     (8, 64, 64, 64, 320, 1, 1, "same", (DMA % "256,128", DMA % "128,64", "k_conv_wgrad+rwide")),                        # 256x128 tiles (N = 320 pads badly to 512)
     (6, 128, 128, 128, 64, 1, 1, "same", (DMA % "256,64", DMA % "256,128", "k_conv_wgrad+rwide")),                      # 256x64 tiles

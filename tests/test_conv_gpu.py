@@ -134,6 +134,62 @@ def test_conv_full_size_dispatch(ops, case):
     assert (db.cpu() - br.grad).abs().max().item() <= 1e-3 * max(1.0, br.grad.abs().max().item()), "bias grad"
 
 
+# (B, H, Cin, Cout, forward on k_pw_gemm, data gradient on k_pw_gemm)
+PW_SHAPES = [(64, 38, 512, 512, True, True), (64, 19, 1024, 1024, True, True), (64, 19, 256, 1024, True, False),
+             (64, 19, 1024, 256, False, True), (70, 19, 320, 320, True, True), (71, 19, 320, 512, True, True)]
+
+
+@pytest.mark.parametrize("shape", PW_SHAPES, ids=[str(s) for s in PW_SHAPES])
+def test_pw_gemm_equals_the_generic_kernels(ops, shape):
+    """k_pw_gemm (persistent 1x1 GEMM: the LDS-DMA stream runs across tile boundaries, wave-private store stage, bias / ReLU
+    sign bytes through LDS) accumulates every output element over the same 32-deep k chunks in the same order as the
+    one-tile-per-workgroup implicit-GEMM kernels it replaces, so the two agree BIT FOR BIT -- forward with bias, ReLU and sign
+    bytes; data gradient plain, with the ReLU mask as sign bytes, and accumulating onto an existing gradient -- at the batch-64
+    layer shapes (conv12, conv14 and conv15's data-gradient shape, as forward and as data gradient) and on ragged pixel / channel tiles.  The generic
+    kernels are compared with the fp32 reference in the cases above; the forward here once more, directly."""
+    from ssd_object_detection_amd import _lib
+    from tests.conv_cases import plan_name
+    B, H, Cin, Cout, pw_fwd, pw_dgrad = shape
+    L = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(H * 7 + Cin + Cout)
+    x = torch.randn((B, H, H, Cin), generator=g, device="cuda").relu().bfloat16()
+    w = (torch.randn((Cout, 1, 1, Cin), generator=g, device="cuda") / np.sqrt(Cin)).bfloat16()
+    bias = torch.randn((Cout,), generator=g, device="cuda") * 0.1
+    dy = torch.randn((B, H, H, Cout), generator=g, device="cuda").bfloat16()
+    base = torch.randn((B, H, H, Cin), generator=g, device="cuda").bfloat16()
+    w_t = ops.weight_transpose(w)
+    outs, names = [], []
+    for v in (0, 3):
+        assert L.ssd_dev_knob(b"SSD_CONV_PW", v) == 0
+        try:
+            names.append((plan_name(L, L.ssd_conv2d_fwd_plan(B, H, H, Cin, Cout, 1, 1, 0, 0, H, H, 0, 1 << 25)),
+                          plan_name(L, L.ssd_conv2d_bwd_data_plan(B, H, H, Cin, Cout, 1, 1, 0, 0, H, H, 1, 1 << 25))))
+            bits = torch.zeros((B, H, H, Cout // 8), dtype=torch.uint8, device="cuda")
+            y = ops.conv2d_fwd_relubits(x, w, bias, 1, 0, 0, H, H, bits)
+            y0 = ops.conv2d_fwd(x, w, bias, 1, 0, 0, H, H, False)
+            xbits = ((x > 0).view(B, H, H, Cin // 8, 8).to(torch.uint8) * (2 ** torch.arange(8, device="cuda", dtype=torch.uint8))).sum(-1).to(torch.uint8).contiguous()
+            dx_plain = ops.conv2d_bwd_data(dy, w_t, None, (B, H, H, Cin), 1, 0, 0)
+            dx_bits = ops.conv2d_bwd_data_bits(dy, w_t, xbits, (B, H, H, Cin), 1, 0, 0)
+            acc = base.clone()
+            ops.conv2d_bwd_data_bits(dy, w_t, xbits, (B, H, H, Cin), 1, 0, 0, accumulate=True, out=acc)
+        finally:
+            L.ssd_dev_knob(b"SSD_CONV_PW", 3)
+        outs.append((y, bits, y0, dx_plain, dx_bits, acc))
+    assert (names[1][0] == "k_pw_gemm", names[1][1] == "k_pw_gemm") == (pw_fwd, pw_dgrad), names
+    assert "k_pw_gemm" not in names[0] and "splitk" not in "".join(names[0]), names
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    y, bits = outs[1][0], outs[1][1]
+    want_bits = ((y > 0).view(B, H, H, Cout // 8, 8).to(torch.uint8) * (2 ** torch.arange(8, device="cuda", dtype=torch.uint8))).sum(-1).to(torch.uint8)
+    assert torch.equal(bits, want_bits)
+    assert torch.equal(outs[1][4], outs[1][3] * (x > 0))                       # the sign-byte mask is the ReLU mask
+    with torch.no_grad():
+        yr = (x.float().view(-1, Cin) @ w.float().view(Cout, Cin).t() + bias).relu().view(B, H, H, Cout)
+        assert (y.float() - yr).abs().max().item() <= 2 ** -7 * max(1.0, yr.abs().max().item())
+        dxr = dy.float().view(-1, Cout) @ w.float().view(Cout, Cin)
+        assert (outs[1][3].float().view(-1, Cin) - dxr).abs().max().item() <= 2 ** -7 * max(1.0, dxr.abs().max().item())
+
+
 def test_first_layer_kernels_full_size(ops):
     """The dedicated image-layer kernels (8 padded channels -> 64) at the real map size: more blocks than persistent
     workgroups (several iterations per workgroup), ragged right/bottom blocks, forward and weight gradient."""

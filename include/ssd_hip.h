@@ -261,9 +261,23 @@ int ssd_conv2d_bwd_data_wgrad_first(const void* dy, const void* w_t, const void*
  * pooling that produced the map: dx_full[B,Hf,Wf,Cin] = ssd_maxpool2x2_bwd_argmax(pool_code, ssd_conv2d_bwd_data(...)) in
  * one launch, bit-identical (the un-pooling runs in the convolution's store stage: no pooled gradient in HBM, no second
  * kernel).  Served by the LDS-patch kernels only: SSD_ERR_UNSUPPORTED (nothing launched) for any other layer shape --
- * call the two functions then. */
-int ssd_conv2d_bwd_data_unpool(const void* dy, const void* w_t, const void* relu_src, const void* pool_code, void* dx_full, int B,
-                               int H, int W, int Cin, int Cout_pad, int Hf, int Wf, void* ws, size_t ws_bytes, void* stream);
+ * call the two functions then.
+ * dx_pooled (may be NULL): also receives the gradient w.r.t. the pooled map itself [B,H,W,Cin] -- the compressed form
+ * ssd_conv2d_bwd_weight_unpooled reads. */
+int ssd_conv2d_bwd_data_unpool(const void* dy, const void* w_t, const void* relu_src, const void* pool_code, void* dx_pooled,
+                               void* dx_full, int B, int H, int W, int Cin, int Cout_pad, int Hf, int Wf, void* ws, size_t ws_bytes,
+                               void* stream);
+/* Weight gradient of a 3x3 / stride 1 / pad 1 convolution whose output is 2x2 / stride-2 max-pooled (block1_conv2, block2_conv2,
+ * block3_conv3: models/ssd_model.py:77-84), from the gradient of the POOLED map dpool [B,Hp,Wp,Cout] and the pooling's winner codes
+ * pool_code [B,Hp,Wp,Cout/8] (ssd_maxpool2x2_fwd_argmax / ssd_conv2d_fwd_pool):
+ *   == ssd_conv2d_bwd_weight(x, ssd_maxpool2x2_bwd_argmax(pool_code, dpool), ...)   up to fp32 summation order,
+ * without multiplying the three zeros of every pooling window: the window's four pixels are four consecutive k of a
+ * structured-sparse MFMA (v_smfmac_f32_16x16x64_bf16), the pooled gradient is the compressed operand, the code its index.
+ * Cin, Cout multiples of 64, H, W >= 16, Hp = H/2 or (H+1)/2 (VALID / SAME pooling); SSD_ERR_UNSUPPORTED otherwise (nothing
+ * launched).  Deterministic (fixed-order split reduction). */
+size_t ssd_conv2d_bwd_weight_unpooled_workspace_bytes(int B, int H, int W, int Cin, int Cout, int Hp, int Wp);
+int ssd_conv2d_bwd_weight_unpooled(const void* x, const void* dpool, const void* pool_code, float* dw, float* dbias, int B, int H,
+                                   int W, int Cin, int Cout, int Hp, int Wp, void* ws, size_t ws_bytes, void* stream);
 /* dw f32 [Cout][k][k][Cin], dbias f32 [Cout] (or NULL) from x[B,H,W,Cin] and dy[B,Ho,Wo,ldy] (first Cout
  * channels).  Deterministic (fixed-order split reduction). */
 size_t ssd_conv2d_bwd_weight_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ldy, int ksize);

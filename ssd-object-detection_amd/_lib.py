@@ -75,7 +75,9 @@ _SIGNATURES = {
     "ssd_conv2d_bwd_data": (ctypes.c_int, [VP, VP, VP, VP] + [ctypes.c_int] * 12 + [VP, ctypes.c_size_t, VP]),
     "ssd_conv2d_fwd_relubits": (ctypes.c_int, [VP] * 5 + [ctypes.c_int] * 11 + [VP, ctypes.c_size_t, VP]),
     "ssd_conv2d_bwd_data_bits": (ctypes.c_int, [VP] * 4 + [ctypes.c_int] * 12 + [VP, ctypes.c_size_t, VP]),
-    "ssd_conv2d_bwd_data_unpool": (ctypes.c_int, [VP] * 5 + [ctypes.c_int] * 7 + [VP, ctypes.c_size_t, VP]),
+    "ssd_conv2d_bwd_data_unpool": (ctypes.c_int, [VP] * 6 + [ctypes.c_int] * 7 + [VP, ctypes.c_size_t, VP]),
+    "ssd_conv2d_bwd_weight_unpooled_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 7),
+    "ssd_conv2d_bwd_weight_unpooled": (ctypes.c_int, [VP] * 5 + [ctypes.c_int] * 7 + [VP, ctypes.c_size_t, VP]),
     "ssd_conv2d_bwd_data_wgrad_first_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
     "ssd_conv2d_bwd_data_wgrad_first": (ctypes.c_int, [VP] * 6 + [ctypes.c_int] * 3 + [VP, ctypes.c_size_t, VP]),
     "ssd_conv2d_bwd_weight_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 7),

@@ -23,3 +23,7 @@ int ssd_knob(const char* name, int dflt);
 bool ssd_pw_gemm_serves(int epi, const void* geom, const void* epilogue);
 int ssd_pw_gemm_launch(int epi, const void* x, const void* w, const void* geom, const void* epilogue, void* ws, size_t ws_bytes,
                        void* stream);
+
+// fixed-order sum of weight-gradient slabs (k_wgrad_reduce2 / k_wgrad_reduce_wide, conv.hip): dW = sum over ns splits
+void ssd_launch_wgrad_reduce(hipStream_t s, const float* slab_w, long long sw, long long nw, float* dw, const float* slab_b,
+                             long long sb, int nb, float* db, int ns);

@@ -2087,7 +2087,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wgrad_patch(const bf16_raw* __r
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
                     reinterpret_cast<s16x4_t*>(&f.fa[a])[half] =
-                        __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + ab[a] + (ks * 2 + half) * 2048));
+                        lds_read_tr16_scoped(smem + ab[a] + (ks * 2 + half) * 2048, smem);
 #pragma unroll
             for (int t5 = 0; t5 < NTAP; ++t5)
 #pragma unroll
@@ -2097,7 +2097,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wgrad_patch(const bf16_raw* __r
                     const int rp = pg / BW8, xg = pg - rp * BW8;
                     const int ctap = (2 * rp + tap / 3) * G::PW + xg * 8 + (tap % 3);   // compile-time pixel offset
                     reinterpret_cast<s16x4_t*>(&f.fb[t5])[half] =
-                        __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + gb[ctap & 7] + (ctap >> 3) * 1024));
+                        lds_read_tr16_scoped(smem + gb[ctap & 7] + (ctap >> 3) * 1024, smem);
                 }
         };
         for (int t = t_begin; t < t_end; ++t) {
@@ -2265,7 +2265,7 @@ __global__ __launch_bounds__(512) void k_conv0_wgrad(const bf16_raw* __restrict_
         bbase[t] = W0_DY + (p0 + (tap / 3) * PATCH_W + tap % 3) * 16 + (li & 1) * 8;
     }
     typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
-    auto rd = [&](int addr) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + addr)); };
+    auto rd = [&](int addr) { return lds_read_tr16_scoped(smem + addr, smem); };
 
     if (t_begin < t_end) issue_dma(t_begin, 0);
     for (int t = t_begin; t < t_end; ++t) {
@@ -2659,7 +2659,7 @@ Knob g_knobs[] = {{"SSD_ABLATE", {KNOB_UNSET}}, {"SSD_DGRAD_S2", {KNOB_UNSET}},
                   {"SSD_CONV_PATCH_FLAT", {KNOB_UNSET}}, {"SSD_WGRAD_FIRST", {KNOB_UNSET}}, {"SSD_CONV_FIRST", {KNOB_UNSET}},
                   {"SSD_WGRAD_PATCH_XCD", {KNOB_UNSET}}, {"SSD_CONV_C64", {KNOB_UNSET}}, {"SSD_CONV_POOL_FUSE", {KNOB_UNSET}},
                   {"SSD_CONV_PATCH_ROWFLAT", {KNOB_UNSET}}, {"SSD_MATCH_FUSED", {KNOB_UNSET}}, {"SSD_CONV_P512", {KNOB_UNSET}},
-                  {"SSD_C64B_WGS", {KNOB_UNSET}}, {"SSD_CONV_PW", {KNOB_UNSET}}, {"SSD_PW_WGS", {KNOB_UNSET}}, {"SSD_PW_DYNAMIC", {KNOB_UNSET}}};
+                  {"SSD_C64B_WGS", {KNOB_UNSET}}, {"SSD_CONV_PW", {KNOB_UNSET}}, {"SSD_PW_WGS", {KNOB_UNSET}}, {"SSD_PW_DYNAMIC", {KNOB_UNSET}}, {"SSD_SP_ABLATE", {KNOB_UNSET}}};
 Knob* find_knob(const char* name) {
     for (Knob& k : g_knobs) if (!strcmp(k.name, name)) return &k;
     return nullptr;
@@ -2891,6 +2891,17 @@ bool geom_ok(int B, int H, int W, int C, int Ho, int Wo, int N, int K) {
 
 int ssd_knob(const char* name, int dflt) { return knob(name, dflt); }
 
+void ssd_launch_wgrad_reduce(hipStream_t s, const float* slab_w, long long sw, long long nw, float* dw, const float* slab_b,
+                             long long sb, int nb, float* db, int ns) {
+    if (ns >= 32) {
+        const unsigned nbw = (unsigned)((nw / 4 + 15) / 16), nbb = db ? (unsigned)((nb + 15) / 16) : 0u;
+        hipLaunchKernelGGL(k_wgrad_reduce_wide, dim3(nbw + nbb), dim3(256), 0, s, slab_w, sw, nw, dw, slab_b, sb, nb, db, ns, nbw);
+    } else {
+        const unsigned nbw = (unsigned)((nw / 4 + 255) / 256), nbb = db ? (unsigned)((nb + 255) / 256) : 0u;
+        hipLaunchKernelGGL(k_wgrad_reduce2, dim3(nbw + nbb), dim3(256), 0, s, slab_w, sw, nw, dw, slab_b, sb, nb, db, ns, nbw);
+    }
+}
+
 extern "C" {
 
 int ssd_dev_knob(const char* name, int value) {
@@ -3011,15 +3022,16 @@ int ssd_conv2d_bwd_data_bits(const void* dy, const void* w_t, const void* relu_b
                                 ws_bytes, stream, nullptr, nullptr, nullptr, 0, 0, relu_bits);
 }
 
-int ssd_conv2d_bwd_data_unpool(const void* dy, const void* w_t, const void* relu_src, const void* pool_code, void* dx_full, int B,
-                               int H, int W, int Cin, int Cout_pad, int Hf, int Wf, void* ws, size_t ws_bytes, void* stream) {
+int ssd_conv2d_bwd_data_unpool(const void* dy, const void* w_t, const void* relu_src, const void* pool_code, void* dx_pooled,
+                               void* dx_full, int B, int H, int W, int Cin, int Cout_pad, int Hf, int Wf, void* ws, size_t ws_bytes,
+                               void* stream) {
     // 3x3 / stride 1 / pad 1 data gradient w.r.t. a POOLED map [B,H,W,Cin], carried on through the 2x2 / stride-2 max pooling
     // that produced the map (pool_code [B,H,W,Cin/8] of ssd_maxpool2x2_fwd_argmax / ssd_conv2d_fwd_pool): dx_full [B,Hf,Wf,Cin]
     if (!pool_code || !dx_full || Cin % 8 || Hf <= 0 || Wf <= 0) return SSD_ERR_VALUE;
     if ((H != Hf / 2 && H != (Hf + 1) / 2) || (W != Wf / 2 && W != (Wf + 1) / 2)) return SSD_ERR_VALUE;
     if (2 * H < Hf || 2 * W < Wf) return SSD_ERR_UNSUPPORTED;     // VALID pooling of an odd size: the uncovered row / column is not written here
     if ((long long)B * Hf * Wf * Cin >= (1ll << 32)) return SSD_ERR_VALUE;
-    return conv2d_bwd_data_impl(dy, w_t, relu_src, nullptr, B, H, W, Cin, Cout_pad, 3, 1, 1, 1, H, W, 0, ws, ws_bytes, stream, nullptr,
+    return conv2d_bwd_data_impl(dy, w_t, relu_src, dx_pooled, B, H, W, Cin, Cout_pad, 3, 1, 1, 1, H, W, 0, ws, ws_bytes, stream, nullptr,
                                 pool_code, dx_full, Hf, Wf);
 }
 
@@ -3037,13 +3049,7 @@ static int wgrad_patch_min_hw() {           // SSD_WGRAD_PATCH = smallest featur
 // dW / dbias = sum over splits of the slabs, fixed order
 static void launch_wgrad_reduce(hipStream_t s, const float* slab_w, long long sw, long long nw, float* dw, const float* slab_b,
                                 long long sb, int nb, float* db, int ns) {
-    if (ns >= 32) {
-        const unsigned nbw = (unsigned)((nw / 4 + 15) / 16), nbb = db ? (unsigned)((nb + 15) / 16) : 0u;
-        hipLaunchKernelGGL(k_wgrad_reduce_wide, dim3(nbw + nbb), dim3(256), 0, s, slab_w, sw, nw, dw, slab_b, sb, nb, db, ns, nbw);
-    } else {
-        const unsigned nbw = (unsigned)((nw / 4 + 255) / 256), nbb = db ? (unsigned)((nb + 255) / 256) : 0u;
-        hipLaunchKernelGGL(k_wgrad_reduce2, dim3(nbw + nbb), dim3(256), 0, s, slab_w, sw, nw, dw, slab_b, sb, nb, db, ns, nbw);
-    }
+    ssd_launch_wgrad_reduce(s, slab_w, sw, nw, dw, slab_b, sb, nb, db, ns);
 }
 
 // Data gradient of the second layer (64 -> 64, 3x3 / stride 1 / pad 1) fused with the weight gradient of the first

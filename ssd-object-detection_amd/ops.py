@@ -513,7 +513,7 @@ def conv2d_bwd_data_wgrad_first(dy, w_t, bits, image, dw=None, dbias=None, ws=No
     return dw, dbias
 
 
-def conv2d_bwd_data_unpool(dy, w_t, relu_src, pool_code, full_shape, out=None, ws=None):
+def conv2d_bwd_data_unpool(dy, w_t, relu_src, pool_code, full_shape, out=None, ws=None, pooled_out=None):
     """conv2d_bwd_data (3x3 / stride 1 / pad 1) w.r.t. a pooled map followed by maxpool2x2_bwd_argmax, in one launch: returns the
     gradient of the map BEFORE the pooling ([B,Hf,Wf,Cin]).  Raises NotImplementedError (SSD_ERR_UNSUPPORTED, nothing launched)
     when the layer is not served by an LDS-patch kernel: use the two calls then."""
@@ -525,8 +525,11 @@ def conv2d_bwd_data_unpool(dy, w_t, relu_src, pool_code, full_shape, out=None, w
     if out is None:
         out = torch.empty(full_shape, dtype=torch.bfloat16, device=dy.device)
     wbuf = _splitk_ws(ws)
-    rc = L.ssd_conv2d_bwd_data_unpool(_ptr(dy), _ptr(w_t), _ptr(relu_src), _ptr(pool_code), _ptr(out), B, H, W, Cin, cpad, Hf, Wf,
-                                      _ptr(wbuf), wbuf.numel(), _stream())
+    if pooled_out is not None:                     # also keep the gradient of the pooled map (conv2d_bwd_weight_unpooled reads it)
+        _bf(pooled_out)
+        assert pooled_out.shape == (B, H, W, Cin)
+    rc = L.ssd_conv2d_bwd_data_unpool(_ptr(dy), _ptr(w_t), _ptr(relu_src), _ptr(pool_code), _ptr(pooled_out), _ptr(out), B, H, W, Cin,
+                                      cpad, Hf, Wf, _ptr(wbuf), wbuf.numel(), _stream())
     if rc == _lib.SSD_ERR_UNSUPPORTED:
         raise NotImplementedError("no LDS-patch kernel for this layer")
     _lib.check(rc)
@@ -546,6 +549,31 @@ def conv2d_bwd_weight(x, dy, Cout, k, stride, pad_t, pad_l, dw=None, dbias=None,
     wbuf = (ws or _conv_ws).get(nbytes, x.device)
     _lib.check(L.ssd_conv2d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(dbias), B, H, W, Cin, Cout, ldy, k, stride,
                                        pad_t, pad_l, Ho, Wo, _ptr(wbuf), wbuf.numel(), _stream()))
+    return dw, dbias
+
+
+def conv2d_bwd_weight_unpooled(x, dpool, pool_code, dw=None, dbias=None, want_bias=True, ws=None):
+    """Weight gradient of a 3x3 / stride 1 / pad 1 convolution whose output was 2x2 max-pooled, from the gradient of the pooled
+    map and the winner codes (== conv2d_bwd_weight(x, maxpool2x2_bwd_argmax(pool_code, dpool, ...)) without the un-pooled zeros:
+    structured-sparse MFMA).  Raises NotImplementedError (SSD_ERR_UNSUPPORTED, nothing launched) for shapes it does not serve."""
+    L = _lib.lib()
+    _bf(x); _bf(dpool)
+    B, H, W, Cin = x.shape
+    _, Hp, Wp, Cout = dpool.shape
+    assert pool_code.shape == (B, Hp, Wp, Cout // 8) and pool_code.dtype == torch.int32
+    if dw is None:
+        dw = torch.empty((Cout, 3, 3, Cin), dtype=torch.float32, device=x.device)
+    if dbias is None and want_bias:
+        dbias = torch.empty((Cout,), dtype=torch.float32, device=x.device)
+    nbytes = L.ssd_conv2d_bwd_weight_unpooled_workspace_bytes(B, H, W, Cin, Cout, Hp, Wp)
+    if nbytes == 0:
+        raise NotImplementedError("no structured-sparse weight-gradient kernel for this layer")
+    wbuf = (ws or _conv_ws).get(nbytes, x.device)
+    rc = L.ssd_conv2d_bwd_weight_unpooled(_ptr(x), _ptr(dpool), _ptr(pool_code), _ptr(dw), _ptr(dbias), B, H, W, Cin, Cout, Hp, Wp,
+                                          _ptr(wbuf), wbuf.numel(), _stream())
+    if rc == _lib.SSD_ERR_UNSUPPORTED:
+        raise NotImplementedError("no structured-sparse weight-gradient kernel for this layer")
+    _lib.check(rc)
     return dw, dbias
 
 

@@ -313,6 +313,20 @@ int ssd_maxpool2x2_bwd(const void* x, const void* y, const void* dy, void* dx, i
 int ssd_maxpool2x2_fwd_argmax(const void* x, void* y, void* code, int B, int H, int W, int C, int Ho, int Wo, void* stream);
 int ssd_maxpool2x2_bwd_argmax(const void* code, const void* dy, void* dx, int B, int H, int W, int C, int Ho, int Wo,
                               void* stream);
+/* Pieces of a ResNet-50 trunk (BASELINE configs[4]; the reference hard-codes its VGG trunk, models/ssd_model.py:46,75-97, so these
+ * have no reference counterpart: semantics are Keras / TensorFlow's Add + ReLU, MaxPooling2D(3, strides=2, padding="same") and
+ * their tape.gradient).  bf16 NHWC, n = element count (a multiple of 8).
+ *   ssd_add_relu_fwd      out = relu(a + b)                               (residual add of a bottleneck block)
+ *   ssd_relu_mask_bwd     out (+)= g where act > 0                        (its gradient on the identity-skip branch)
+ *   ssd_maxpool3x3s2_fwd  3x3 / stride-2 max pooling with explicit top / left padding; code u32 [B*Ho*Wo*C/8]: one nibble per
+ *                         element = 3 dy + dx of the first maximum, 15 = maximum <= 0 (no gradient through the ReLU in front)
+ *   ssd_maxpool3x3s2_bwd  dx = gather of dy over the (overlapping) windows whose winner is the pixel: deterministic */
+int ssd_add_relu_fwd(const void* a, const void* b, void* out, long long n, void* stream);
+int ssd_relu_mask_bwd(const void* g, const void* act, void* out, int accumulate, long long n, void* stream);
+int ssd_maxpool3x3s2_fwd(const void* x, void* y, void* code, int B, int H, int W, int C, int Ho, int Wo, int pad_t, int pad_l,
+                         void* stream);
+int ssd_maxpool3x3s2_bwd(const void* code, const void* dy, void* dx, int B, int H, int W, int C, int Ho, int Wo, int pad_t, int pad_l,
+                         void* stream);
 /* ------------------------------------------------------------------------------------------
  * Backward pass of ALL head convolutions (models/ssd_model.py:153-162; 3x3, stride 1, SAME, no activation) from the compact
  * gradient rows of ssd_loss_fwd_bwd_heads -- the part of tape.gradient (:248) behind the loc / conf outputs.  Work is

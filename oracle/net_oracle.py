@@ -60,3 +60,34 @@ def forward(trunk, num_priors, classes, params, image_nhwc, emulate_bf16=True):
         locs.append(y[..., :n * 4].reshape(B, -1, 4))                   # Reshape((-1, 4)), :166
         confs.append(y[..., n * 4:].reshape(B, -1, classes))            # Reshape((-1, classes)), :167
     return torch.cat(locs, 1), torch.cat(confs, 1)
+
+
+def forward_graph(graph, num_priors, classes, params, image_nhwc, emulate_bf16=True):
+    """The same for a DAG trunk (resnet_engine.resnet50_ssd512_graph: ResNet-50 v1.5 with folded batch norm + SSD extras; no
+    reference counterpart, the reference hard-codes its VGG chain): nodes dict(op = conv | pool3 | add, src, k, stride, relu,
+    feature), conv{i} named by node index.  Keras / TF semantics: SAME padding, MaxPooling2D(3, 2, "same"), Add + ReLU."""
+    rnd = _RoundBF16.apply if emulate_bf16 else (lambda t: t)
+    outs = {-1: image_nhwc.permute(0, 3, 1, 2)}
+    feats = []
+    for i, nd in enumerate(graph):
+        if nd["op"] == "conv":
+            y = conv_tf(outs[nd["src"]], params["conv%d/kernel" % i], params["conv%d/bias" % i], nd["k"], nd["stride"], True, nd["relu"])
+        elif nd["op"] == "pool3":
+            x = outs[nd["src"]]
+            _, pt, pb = _same_pad(x.shape[2], 3, 2)
+            _, pl, pr = _same_pad(x.shape[3], 3, 2)
+            y = F.max_pool2d(F.pad(x, (pl, pr, pt, pb), value=float("-inf")), 3, 2)
+        else:
+            a, sc = nd["src"]
+            y = (outs[a] + outs[sc]).relu()
+        outs[i] = rnd(y)
+        if nd["feature"]:
+            feats.append(outs[i])
+    locs, confs = [], []
+    B = image_nhwc.shape[0]
+    for lvl, (f, n) in enumerate(zip(feats, num_priors)):
+        y = conv_tf(f, params["head%d/kernel" % lvl], params["head%d/bias" % lvl], 3, 1, True, False)
+        y = rnd(y).permute(0, 2, 3, 1)
+        locs.append(y[..., :n * 4].reshape(B, -1, 4))
+        confs.append(y[..., n * 4:].reshape(B, -1, classes))
+    return torch.cat(locs, 1), torch.cat(confs, 1)

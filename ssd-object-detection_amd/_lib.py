@@ -76,6 +76,10 @@ _SIGNATURES = {
     "ssd_conv2d_fwd_relubits": (ctypes.c_int, [VP] * 5 + [ctypes.c_int] * 11 + [VP, ctypes.c_size_t, VP]),
     "ssd_conv2d_bwd_data_bits": (ctypes.c_int, [VP] * 4 + [ctypes.c_int] * 12 + [VP, ctypes.c_size_t, VP]),
     "ssd_conv2d_bwd_data_unpool": (ctypes.c_int, [VP] * 6 + [ctypes.c_int] * 7 + [VP, ctypes.c_size_t, VP]),
+    "ssd_add_relu_fwd": (ctypes.c_int, [VP, VP, VP, ctypes.c_longlong, VP]),
+    "ssd_relu_mask_bwd": (ctypes.c_int, [VP, VP, VP, ctypes.c_int, ctypes.c_longlong, VP]),
+    "ssd_maxpool3x3s2_fwd": (ctypes.c_int, [VP, VP, VP] + [ctypes.c_int] * 8 + [VP]),
+    "ssd_maxpool3x3s2_bwd": (ctypes.c_int, [VP, VP, VP] + [ctypes.c_int] * 8 + [VP]),
     "ssd_conv2d_bwd_weight_unpooled_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 7),
     "ssd_conv2d_bwd_weight_unpooled": (ctypes.c_int, [VP] * 5 + [ctypes.c_int] * 7 + [VP, ctypes.c_size_t, VP]),
     "ssd_conv2d_bwd_data_wgrad_first_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),

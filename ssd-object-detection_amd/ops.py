@@ -645,6 +645,57 @@ def maxpool2x2_bwd(x, y, dy, out=None):
     return out
 
 
+def add_relu_fwd(a, b, out=None):
+    """out = relu(a + b): the residual add of a ResNet bottleneck (bf16, any equal shapes with a multiple of 8 elements)."""
+    L = _lib.lib()
+    _bf(a); _bf(b)
+    assert a.shape == b.shape
+    if out is None:
+        out = torch.empty_like(a)
+    _lib.check(L.ssd_add_relu_fwd(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()))
+    return out
+
+
+def relu_mask_bwd(g, act, out=None, accumulate=False):
+    """out (+)= g * (act > 0): the gradient of relu(a + b) w.r.t. an identity-skip input whose own activation is `act`."""
+    L = _lib.lib()
+    _bf(g); _bf(act)
+    assert g.shape == act.shape
+    if out is None:
+        assert not accumulate
+        out = torch.empty_like(g)
+    _lib.check(L.ssd_relu_mask_bwd(_ptr(g), _ptr(act), _ptr(out), 1 if accumulate else 0, g.numel(), _stream()))
+    return out
+
+
+def maxpool3x3s2_fwd(x, out=None, code=None):
+    """MaxPooling2D(3, strides=2, padding="same") (TF padding: the odd cell goes to the bottom / right); returns (y, code)."""
+    L = _lib.lib()
+    _bf(x)
+    B, H, W, C = x.shape
+    Ho, pt = same_pad(H, 3, 2)
+    Wo, pl = same_pad(W, 3, 2)
+    if out is None:
+        out = torch.empty((B, Ho, Wo, C), dtype=torch.bfloat16, device=x.device)
+    if code is None:
+        code = torch.empty((B, Ho, Wo, C // 8), dtype=torch.int32, device=x.device)
+    _lib.check(L.ssd_maxpool3x3s2_fwd(_ptr(x), _ptr(out), _ptr(code), B, H, W, C, Ho, Wo, pt, pl, _stream()))
+    return out, code
+
+
+def maxpool3x3s2_bwd(code, dy, x_shape, out=None):
+    L = _lib.lib()
+    _bf(dy)
+    B, H, W, C = x_shape
+    Ho, pt = same_pad(H, 3, 2)
+    Wo, pl = same_pad(W, 3, 2)
+    assert dy.shape == (B, Ho, Wo, C) and code.shape == (B, Ho, Wo, C // 8)
+    if out is None:
+        out = torch.empty(x_shape, dtype=torch.bfloat16, device=dy.device)
+    _lib.check(L.ssd_maxpool3x3s2_bwd(_ptr(code), _ptr(dy), _ptr(out), B, H, W, C, Ho, Wo, pt, pl, _stream()))
+    return out
+
+
 def head_grad_pack(dloc, dconf, hw, per_cell, classes, npad, level_off, out=None):
     L = _lib.lib()
     _bf(dloc); _bf(dconf)

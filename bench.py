@@ -624,6 +624,31 @@ def cfg5_section(torch, ops, B):
         eng.adam(1e-3, eng.grad, 1.0, True)
     t_step = timed(torch, step512, 5, warm=2)
     del eng
+    # configs[4]'s "fp8 MFMA convs": the >= 256-channel 3x3 layers of that trunk forward in block-scaled fp8 (MX e4m3 on
+    # v_mfma_scale_f32_16x16x128_f8f6f4, csrc/fp8conv.hip) beside the bf16 kernels, batch 16; activations are quantised per call
+    # (timed separately), the filters once.  Error vs fp32: tests/test_fp8_gpu.py (3.7e-2 relative L2 from the format itself).
+    fp8 = {"layers": [], "note": "first correct kernel: the generic 128x128 implicit GEMM at one byte per element, no LDS patch reuse"}
+    tot8 = tot16 = totq = flops = 0.0
+    for name, Hh, Cin, Cout in (("block3_conv2", 128, 256, 256), ("block3_conv3", 128, 256, 256), ("conv10", 64, 256, 512), ("conv11", 64, 512, 512)):
+        xx = torch.randn((Bs, Hh, Hh, Cin), device="cuda").relu().bfloat16()
+        ww = (torch.randn((Cout, 3, 3, Cin), device="cuda") / (9 * Cin) ** 0.5).bfloat16()
+        bb = torch.zeros(Cout, device="cuda")
+        wq, ws8 = ops.quantize_mx_fp8(ww)
+        xq, xs8 = ops.quantize_mx_fp8(xx)
+        y8 = ops.conv3x3_fwd_mxfp8(xq, xs8, wq, ws8, bb)
+        y16 = ops.conv2d_fwd(xx, ww, bb, 1, 1, 1, Hh, Hh, True)
+        t8 = timed(torch, lambda: ops.conv3x3_fwd_mxfp8(xq, xs8, wq, ws8, bb, out=y8), 10)
+        t16 = timed(torch, lambda: ops.conv2d_fwd(xx, ww, bb, 1, 1, 1, Hh, Hh, True, out=y16), 10)
+        tq = timed(torch, lambda: ops.quantize_mx_fp8(xx), 10)
+        fl = 2.0 * Bs * Hh * Hh * Cout * 9 * Cin
+        err = float((y8.float() - y16.float()).norm() / y16.float().norm())
+        fp8["layers"].append({"layer": name, "shape": [Bs, Hh, Hh, Cin, Cout], "fp8_us": round(t8 * 1e6, 1), "bf16_us": round(t16 * 1e6, 1),
+                              "quantise_input_us": round(tq * 1e6, 1), "fp8_tflops": round(fl / t8 / 1e12, 1),
+                              "bf16_tflops": round(fl / t16 / 1e12, 1), "rel_l2_vs_bf16_kernel": round(err, 4)})
+        tot8 += t8; tot16 += t16; totq += tq; flops += fl
+        del xx, ww, xq, xs8, y8, y16
+    fp8.update({"fp8_us": round(tot8 * 1e6, 1), "bf16_us": round(tot16 * 1e6, 1), "quantise_us": round(totq * 1e6, 1),
+                "fp8_tflops": round(flops / tot8 / 1e12, 1), "frac_of_fp8_peak_5PF": round(flops / tot8 / 5e15, 4)})
     return {"train_step": {"workload": "SSD recipe at 512x512, 7 levels, %d anchors, batch %d, bf16 (VGG-style trunk, engine.SSD512_TRUNK): "
                                        "match + prep + fwd + loss + bwd + 72-variable clip + Adam" % (A, Bs),
                            "images_per_sec": round(Bs / t_step, 1), "ms_per_step": round(t_step * 1e3, 3)},
@@ -632,7 +657,7 @@ def cfg5_section(torch, ops, B):
             "match_encode_us_per_image": round(t_match / B * 1e6, 4), "match_GBs": round(mbytes / t_match / 1e9, 1),
             "loss_us_per_image": round(t_loss / B * 1e6, 4), "loss_GBs": round(lbytes / t_loss / 1e9, 1),
             "score_decode_us_per_image": round(t_sd / B * 1e6, 4), "nms_us_per_image": round(t_nms / B * 1e6, 4),
-            "candidates_per_image": round(float(cand.sum().item()) / B, 1)}
+            "candidates_per_image": round(float(cand.sum().item()) / B, 1), "fp8_forward": fp8}
 
 
 def _usable_cores():

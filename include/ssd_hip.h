@@ -313,6 +313,16 @@ int ssd_maxpool2x2_bwd(const void* x, const void* y, const void* dy, void* dx, i
 int ssd_maxpool2x2_fwd_argmax(const void* x, void* y, void* code, int B, int H, int W, int C, int Ho, int Wo, void* stream);
 int ssd_maxpool2x2_bwd_argmax(const void* code, const void* dy, void* dx, int B, int H, int W, int C, int Ho, int Wo,
                               void* stream);
+/* Block-scaled fp8 forward convolution (BASELINE configs[4]: "fp8 MFMA convs"; no reference counterpart -- the reference's
+ * convolutions are fp32 TensorFlow ops, models/ssd_model.py:86-93 for the >= 256-channel 3x3 layers this serves).  MX format: OCP
+ * e4m3 elements, one E8M0 scale byte (2^(s-127)) per 32 consecutive channels, multiplied on v_mfma_scale_f32_16x16x128_f8f6f4.
+ *   ssd_quantize_mx_fp8     x bf16 [n] (n % 32 == 0) -> q u8 [n], scale u8 [n/32]: scale = smallest power of two with |x|/scale <= 448
+ *   ssd_conv3x3_fwd_mxfp8   y bf16 [B,H,W,Cout] = relu?(conv3x3 SAME stride 1 of x with w + bias); x8 [B,H,W,Cin] / xscale [B,H,W,Cin/32],
+ *                           w8 [Cout][3][3][Cin] / wscale [Cout][3][3][Cin/32] as ssd_quantize_mx_fp8 makes them; Cin % 128 == 0,
+ *                           Cout % 8 == 0 (SSD_ERR_UNSUPPORTED otherwise); fp32 accumulation */
+int ssd_quantize_mx_fp8(const void* x_bf16, void* q, void* scale, long long n, void* stream);
+int ssd_conv3x3_fwd_mxfp8(const void* x8, const void* xscale, const void* w8, const void* wscale, const float* bias, void* y, int B,
+                          int H, int W, int Cin, int Cout, int relu, void* stream);
 /* Pieces of a ResNet-50 trunk (BASELINE configs[4]; the reference hard-codes its VGG trunk, models/ssd_model.py:46,75-97, so these
  * have no reference counterpart: semantics are Keras / TensorFlow's Add + ReLU, MaxPooling2D(3, strides=2, padding="same") and
  * their tape.gradient).  bf16 NHWC, n = element count (a multiple of 8).

@@ -76,6 +76,8 @@ _SIGNATURES = {
     "ssd_conv2d_fwd_relubits": (ctypes.c_int, [VP] * 5 + [ctypes.c_int] * 11 + [VP, ctypes.c_size_t, VP]),
     "ssd_conv2d_bwd_data_bits": (ctypes.c_int, [VP] * 4 + [ctypes.c_int] * 12 + [VP, ctypes.c_size_t, VP]),
     "ssd_conv2d_bwd_data_unpool": (ctypes.c_int, [VP] * 6 + [ctypes.c_int] * 7 + [VP, ctypes.c_size_t, VP]),
+    "ssd_quantize_mx_fp8": (ctypes.c_int, [VP, VP, VP, ctypes.c_longlong, VP]),
+    "ssd_conv3x3_fwd_mxfp8": (ctypes.c_int, [VP] * 6 + [ctypes.c_int] * 6 + [VP]),
     "ssd_add_relu_fwd": (ctypes.c_int, [VP, VP, VP, ctypes.c_longlong, VP]),
     "ssd_relu_mask_bwd": (ctypes.c_int, [VP, VP, VP, ctypes.c_int, ctypes.c_longlong, VP]),
     "ssd_maxpool3x3s2_fwd": (ctypes.c_int, [VP, VP, VP] + [ctypes.c_int] * 8 + [VP]),

@@ -645,6 +645,42 @@ def maxpool2x2_bwd(x, y, dy, out=None):
     return out
 
 
+def quantize_mx_fp8(x):
+    """bf16 tensor (last dimension a multiple of 32) -> (q uint8 same shape: OCP e4m3 bytes, scale uint8 [..., C/32]: E8M0)."""
+    L = _lib.lib()
+    _bf(x)
+    assert x.shape[-1] % 32 == 0
+    q = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    scale = torch.empty(x.shape[:-1] + (x.shape[-1] // 32,), dtype=torch.uint8, device=x.device)
+    _lib.check(L.ssd_quantize_mx_fp8(_ptr(x), _ptr(q), _ptr(scale), x.numel(), _stream()))
+    return q, scale
+
+
+def dequantize_mx_fp8(q, scale):
+    """The float32 values an MX-fp8 pair stands for (tests / reports; torch's float8_e4m3fn is the same OCP encoding)."""
+    v = q.view(torch.float8_e4m3fn).float()
+    s = torch.exp2(scale.float() - 127.0)
+    return (v.view(*scale.shape, 32) * s.unsqueeze(-1)).view(q.shape)
+
+
+def conv3x3_fwd_mxfp8(xq, xs, wq, ws, bias, relu=True, out=None):
+    """3x3 / stride 1 / SAME forward on block-scaled fp8 operands (quantize_mx_fp8 of x [B,H,W,Cin] and w [Cout,3,3,Cin])."""
+    L = _lib.lib()
+    B, H, W, Cin = xq.shape
+    Cout = wq.shape[0]
+    assert wq.shape == (Cout, 3, 3, Cin) and xs.shape == (B, H, W, Cin // 32) and ws.shape == (Cout, 3, 3, Cin // 32)
+    for t in (xq, xs, wq, ws):
+        _dev(t, torch.uint8)
+    if out is None:
+        out = torch.empty((B, H, W, Cout), dtype=torch.bfloat16, device=xq.device)
+    rc = L.ssd_conv3x3_fwd_mxfp8(_ptr(xq), _ptr(xs), _ptr(wq), _ptr(ws), _ptr(bias), _ptr(out), B, H, W, Cin, Cout, 1 if relu else 0,
+                                 _stream())
+    if rc == _lib.SSD_ERR_UNSUPPORTED:
+        raise NotImplementedError("block-scaled fp8 forward needs Cin % 128 == 0")
+    _lib.check(rc)
+    return out
+
+
 def add_relu_fwd(a, b, out=None):
     """out = relu(a + b): the residual add of a ResNet bottleneck (bf16, any equal shapes with a multiple of 8 elements)."""
     L = _lib.lib()

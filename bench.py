@@ -624,6 +624,13 @@ def cfg5_section(torch, ops, B):
         eng.adam(1e-3, eng.grad, 1.0, True)
     t_step = timed(torch, step512, 5, warm=2)
     del eng
+    # the same step on configs[4]'s own trunk: ResNet-50 (resnet_engine.py: single stream, no fused schedule yet)
+    from ssd_object_detection_amd.resnet_engine import ResNet50SSDEngine
+    eng = ResNet50SSDEngine(classes=81, seed=0)
+    assert eng.A == A
+    t_step_r50 = timed(torch, step512, 3, warm=2)
+    n_r50 = eng.n_params
+    del eng
     # configs[4]'s "fp8 MFMA convs": the >= 256-channel 3x3 layers of that trunk forward in block-scaled fp8 (MX e4m3 on
     # v_mfma_scale_f32_16x16x128_f8f6f4, csrc/fp8conv.hip) beside the bf16 kernels, batch 16; activations are quantised per call
     # (timed separately), the filters once.  Error vs fp32: tests/test_fp8_gpu.py (3.7e-2 relative L2 from the format itself).
@@ -652,8 +659,11 @@ def cfg5_section(torch, ops, B):
     return {"train_step": {"workload": "SSD recipe at 512x512, 7 levels, %d anchors, batch %d, bf16 (VGG-style trunk, engine.SSD512_TRUNK): "
                                        "match + prep + fwd + loss + bwd + 72-variable clip + Adam" % (A, Bs),
                            "images_per_sec": round(Bs / t_step, 1), "ms_per_step": round(t_step * 1e3, 3)},
+            "train_step_resnet50": {"workload": "BASELINE configs[4]: SSD512 on a ResNet-50 trunk (v1.5, folded batch norm; %d parameters), 7 levels, "
+                                                "%d anchors, batch %d, bf16: match + prep + fwd + loss + bwd + clip + Adam, one stream" % (n_r50, A, Bs),
+                                    "images_per_sec": round(Bs / t_step_r50, 1), "ms_per_step": round(t_step_r50 * 1e3, 3)},
             "config": {"workload": "BASELINE configs[4] anchors: A=%d (grids 64,32,16,8,4,2,1; per cell 4,6,6,6,6,4,4), batch %d, "
-                                   "anchor-side kernels only (no ResNet-50 / fp8 convolutions); no reference counterpart" % (A, B)},
+                                   "anchor-side kernels; the ResNet-50 trunk and the fp8 forward are the sub-entries beside it; no reference counterpart" % (A, B)},
             "match_encode_us_per_image": round(t_match / B * 1e6, 4), "match_GBs": round(mbytes / t_match / 1e9, 1),
             "loss_us_per_image": round(t_loss / B * 1e6, 4), "loss_GBs": round(lbytes / t_loss / 1e9, 1),
             "score_decode_us_per_image": round(t_sd / B * 1e6, 4), "nms_us_per_image": round(t_nms / B * 1e6, 4),

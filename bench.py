@@ -470,7 +470,7 @@ def kernel_sections(np, torch, ops, model, eng, pset, batches, match_out, B, res
         lbytes = B * pset.A * (2 * 81 * s + 2 * 4 * s + 16 + 4 + 1)
         counts = hgb.count.cpu().tolist()[:hgb.levels]
         moved = B * pset.A * (81 * s + 4 * s + 16 + 4 + 1) + sum(c * p * 2 for c, p in zip(counts, hgb.npad))
-        result["roofline_loss"] = hbm_entry("ssd_loss_fwd_bwd_heads (k_loss_rows, k_loss_hist, k_hg_count/assign, k_loss_grad_rows, k_loss_final)",
+        result["roofline_loss"] = hbm_entry("ssd_loss_fwd_bwd_heads (k_loss_rows, k_loss_hist<2>, <3>, k_hg_count, k_hg_assign, k_loss_grad_rows: six launches, no memset node)",
                                             lbytes, t_loss, B, logits="bf16", batch_us=round(t_loss * 1e6, 2),
                                             dense_gradient_form_us=round(t_dense * 1e6, 2), bytes_moved_by_this_form=int(moved),
                                             gradient_rows_per_level=counts, pixels_per_level=[B * h for h in hgb.hw])

@@ -158,6 +158,9 @@ int ssd_loss_fwd_bwd(const void* conf, const void* loc, int dtype, const int32_t
  *   hg        HOST struct, device pointers inside; rows / maps sized for B*hw rows (every pixel selected)
  *   dtype     SSD_BF16 only
  *   ws        >= ssd_loss_heads_workspace_bytes(B, A, C) bytes
+ *   ws_clean  0: the call clears its histogram words first (a memset node).  1: the caller states they are zero already -- they
+ *             are after a COMPLETED call of this function on the same ws with the same B and A (the last launch re-zeroes
+ *             them), and no other use of ws in between; a wrong 1 gives a wrong mining threshold, not a fault
  * Consumers: ssd_heads_bwd_data_sparse, ssd_heads_bwd_weight_sparse. */
 typedef struct {
     int levels;                               /* <= SSD_MAX_LEVELS; sum of hw*per_cell over the levels == A          */
@@ -172,7 +175,7 @@ typedef struct {
 size_t ssd_loss_heads_workspace_bytes(int B, int A, int C);
 int ssd_loss_fwd_bwd_heads(const void* conf, const void* loc, int dtype, const int32_t* gt_cls, const float* gt_loc,
                            const uint8_t* gt_mask, int B, int A, int C, float grad_scale, float* out8,
-                           const ssd_head_grads* hg, void* ws, size_t ws_bytes, void* stream);
+                           const ssd_head_grads* hg, void* ws, size_t ws_bytes, int ws_clean, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Inference scoring + decode -- replaces the scoring half of SSDObjectDetectionModel.visualize

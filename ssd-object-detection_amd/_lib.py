@@ -117,7 +117,7 @@ _SIGNATURES = {
     "ssd_loss_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "ssd_loss_heads_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "ssd_loss_fwd_bwd_heads": (ctypes.c_int, [VP, VP, ctypes.c_int, VP, VP, VP, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                              ctypes.c_float, VP, _HG, VP, ctypes.c_size_t, VP]),
+                                              ctypes.c_float, VP, _HG, VP, ctypes.c_size_t, ctypes.c_int, VP]),
     "ssd_heads_bwd_data_sparse_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, _HL]),
     "ssd_heads_bwd_data_sparse": (ctypes.c_int, [_HG, _HL, ctypes.c_int, VP, ctypes.c_size_t, VP]),
     "ssd_heads_bwd_weight_sparse_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, _HG, _HL]),

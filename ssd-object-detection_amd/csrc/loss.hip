@@ -29,7 +29,8 @@ constexpr int HB1 = 2048, HB2 = 2048, HB3 = 1024;   // radix digits: 11 + 11 + 1
 // same few addresses (same-address global atomics serialise at ~12 ns each): the level-1 histogram
 // and the positive counter are replicated NREP times (workgroup b uses replica b % NREP) and the
 // streaming kernels run as persistent grids so that each workgroup flushes once.
-constexpr int NREP = 16;
+constexpr int NREP = 4;                      // (16 until round 4: k_loss_hist<2> spent most of its 15 us summing 16 x 8 KB per workgroup; four replicas
+                                             //  put <= 192 same-address flushes on a bin over the ~30 us of k_loss_rows)
 constexpr int H1STRIDE = HB1 + 16;           // [HB1] bins, then [HB1] = P, padded
 constexpr int MAX_PERSIST = 768;             // 3 workgroups per CU
 
@@ -45,6 +46,7 @@ struct LossWs {                              // layout of the caller's workspace
     double* part_l1;                         // [nblk] per-block sum of |pred-gt| over positives
     double* part_neg;                        // [nblk] per-block sum of selected background CE
     size_t zero_bytes;                       // bytes to clear starting at hist1
+    size_t hist_words;                       // 32-bit words from hist1 up to (not including) counters: what the rows form re-zeroes itself
 };
 
 __host__ __device__ inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
@@ -70,6 +72,7 @@ inline size_t loss_ws_layout(size_t n, char* base, LossWs* w) {
         w->hist1 = (int*)p_h1; w->hist1s = (int*)p_h1s; w->hist2 = (int*)p_h2; w->hist3 = (int*)p_h3; w->counters = (int*)p_cnt;
         w->part_pos = (double*)p_pp; w->part_l1 = (double*)p_pl; w->part_neg = (double*)p_pn;
         w->zero_bytes = zero_end - zero_start;
+        w->hist_words = (size_t)(p_cnt - p_h1) / 4;
     }
     return off;
 }
@@ -473,9 +476,11 @@ __device__ __forceinline__ int block_sum_int(int v, int* s4) {
 
 // (also the last step of the radix select: every workgroup evaluates it from the three histograms -- the separate
 // one-workgroup launch cost more than 384 redundant evaluations -- and workgroup (0, 0) stores it for the kernels behind)
-__global__ __launch_bounds__(WG) void k_hg_count(const uint8_t* __restrict__ mask, LossWs w, HeadGradsDev h) {
+__global__ __launch_bounds__(WG) void k_hg_count(const uint8_t* __restrict__ mask, LossWs w, HeadGradsDev h, double* __restrict__ part_neg_il,
+                                                 size_t nblk) {
     __shared__ int s4[4];
     __shared__ int s_scan[WG];
+    __shared__ double s_red[4];
     const int b = blockIdx.x, l = blockIdx.y;
     const Select sel = finish_select(w, s_scan);
     if (b == 0 && l == 0 && threadIdx.x == 0) {
@@ -487,14 +492,40 @@ __global__ __launch_bounds__(WG) void k_hg_count(const uint8_t* __restrict__ mas
     }
     const float tau = __uint_as_float(sel.tau_bits);
     int c = 0;
-    for (int pix = threadIdx.x; pix < h.hw[l]; pix += WG) c += hg_pixel_flag(h, mask, w, l, b, pix, sel, tau) ? 1 : 0;
+    double neg = 0.0;                          // sum of the mined negatives' background CE of this (image, level): the loss's third
+    for (int pix = threadIdx.x; pix < h.hw[l]; pix += WG) {     // scalar no longer waits for the gradient pass
+        const size_t g0 = (size_t)b * h.A + h.off[l] + (size_t)pix * h.n[l];
+        bool f = false;
+        for (int a = 0; a < h.n[l]; ++a) {
+            const bool pos = mask[g0 + a] != 0;
+            const float ce = w.ce_bg[g0 + a];
+            const bool ng = !pos && sel.ok && ce >= tau;
+            f |= sel.ok && (pos || ng);
+            if (ng) neg += (double)ce;
+        }
+        c += f ? 1 : 0;
+    }
     const int tot = block_sum_int(c, s4);
-    if (threadIdx.x == 0) h.img_count[l * h.B + b] = tot;
+    const double bn = block_sum(neg, s_red);
+    // ... and a slice of k_loss_rows' per-block sums (positive CE, L1): the 4 366 partial sums of a batch-64 call reach the
+    // workgroup that writes the scalars as levels x B values each (one workgroup summing them all took 6 us)
+    const int idx = l * h.B + b, nwg = h.levels * h.B;
+    const size_t per = (nblk + nwg - 1) / nwg, i0 = (size_t)idx * per;
+    double pp = 0.0, pl = 0.0;
+    for (size_t i = i0 + threadIdx.x; i < min(nblk, i0 + per); i += WG) { pp += w.part_pos[i]; pl += w.part_l1[i]; }
+    pp = block_sum(pp, s_red);
+    pl = block_sum(pl, s_red);
+    if (threadIdx.x == 0) {
+        h.img_count[idx] = tot;
+        part_neg_il[idx] = bn; part_neg_il[nwg + idx] = pp; part_neg_il[2 * nwg + idx] = pl;
+    }
 }
 
-__global__ __launch_bounds__(WG) void k_hg_assign(const uint8_t* __restrict__ mask, LossWs w, HeadGradsDev h) {
+__global__ __launch_bounds__(WG) void k_hg_assign(const uint8_t* __restrict__ mask, LossWs w, HeadGradsDev h, size_t nblk,
+                                                  const double* __restrict__ part_neg_il, float* __restrict__ out) {
     __shared__ int s4[4];
     __shared__ int s_wave[4];
+    __shared__ double s_red[4];
     const int b = blockIdx.x, l = blockIdx.y;
     const Select sel = load_select(w);
     const float tau = __uint_as_float(sel.tau_bits);
@@ -526,6 +557,27 @@ __global__ __launch_bounds__(WG) void k_hg_assign(const uint8_t* __restrict__ ma
         base += chunk_total;
     }
     if (b == h.B - 1 && threadIdx.x == 0) h.count[l] = base;
+    if (b == 0 && l == 0) {
+        // the loss scalars (k_loss_final's arithmetic, same fixed orders): everything they need exists once k_hg_count has run,
+        // so this workgroup writes them here instead of a one-workgroup launch at the end of the chain
+        double a = 0.0, bb = 0.0, c = 0.0;
+        const int nwg = h.levels * h.B;
+        for (int i = threadIdx.x; i < nwg; i += WG) { c += part_neg_il[i]; a += part_neg_il[nwg + i]; bb += part_neg_il[2 * nwg + i]; }
+        a = block_sum(a, s_red);
+        bb = block_sum(bb, s_red);
+        c = block_sum(c, s_red);
+        if (threadIdx.x == 0) {
+            const double P = (double)w.counters[3];
+            const float l_pos = sel.ok ? (float)(a / P) : 0.f;
+            const float l_loc = sel.ok ? (float)(bb / P) : 0.f;
+            const float l_neg = sel.ok && sel.n_neg > 0 ? (float)(c / (double)sel.n_neg) : 0.f;
+            out[0] = l_loc; out[1] = l_pos; out[2] = l_neg; out[3] = l_loc + l_pos + l_neg;
+            out[4] = (float)P; out[5] = (float)sel.n_neg; out[6] = __uint_as_float(sel.tau_bits);
+            const bool bad = w.counters[2] != 0 || !(fabs(a) < (double)INFINITY) || !(fabs(bb) < (double)INFINITY) || !(fabs(c) < (double)INFINITY);
+            out[7] = bad ? 3.f : (!sel.ok ? 1.f : (sel.tau_bits == 0 ? 2.f : 0.f));
+            w.counters[2] = 0;                 // (the non-finite flag is an atomicOr target: clean for the next call)
+        }
+    }
 }
 
 // Gradient of the selected anchors only, written into the compact rows (the arithmetic of k_loss_grad).
@@ -534,7 +586,6 @@ __global__ __launch_bounds__(WG) void k_loss_grad_rows(const __hip_bfloat16* __r
                                                        const uint8_t* __restrict__ mask, size_t n, int C, float grad_scale,
                                                        LossWs w, HeadGradsDev h) {
     typedef __hip_bfloat16 T;
-    __shared__ double s_red[4];
     const Select sel = load_select(w);
     const size_t row0 = (size_t)blockIdx.x * ROWS;
     const int nrow = (int)min((size_t)ROWS, n - row0);
@@ -543,7 +594,9 @@ __global__ __launch_bounds__(WG) void k_loss_grad_rows(const __hip_bfloat16* __r
     const float inv_p = sel.ok ? grad_scale / P : 0.f;
     const float inv_n = sel.ok && sel.n_neg > 0 ? grad_scale / (float)sel.n_neg : 0.f;
     const int r = threadIdx.x >> 1, half = threadIdx.x & 1;
-    double acc_neg = 0.0;
+    // the histograms are read for the last time by k_hg_count / k_hg_assign: this launch leaves them zeroed for the next call
+    // (ws_clean), which saves the hipMemsetAsync node -- a fill KERNEL -- in front of every call
+    for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < w.hist_words; i += (size_t)gridDim.x * WG) w.hist1[i] = 0;
     if (r < nrow) {
         const size_t g = row0 + r;
         const bool pos = mask[g] != 0;
@@ -578,11 +631,8 @@ __global__ __launch_bounds__(WG) void k_loss_grad_rows(const __hip_bfloat16* __r
                     ol[3] = from_f32<T>(e3 > 0.f ? inv_p : (e3 < 0.f ? -inv_p : 0.f));
                 }
             }
-            if (neg && half == 0) acc_neg = (double)ce;
         }
     }
-    const double bn = block_sum(acc_neg, s_red);
-    if (threadIdx.x == 0) w.part_neg[blockIdx.x] = bn;
 }
 
 // the launches both forms share: conf read once, exact radix select of tau
@@ -625,12 +675,13 @@ size_t ssd_loss_workspace_bytes(int B, int A, int C) {
 
 size_t ssd_loss_heads_workspace_bytes(int B, int A, int C) {
     if (B <= 0 || A <= 0 || C <= 0) return 0;
-    return loss_ws_layout((size_t)B * A, nullptr, nullptr) + al256((size_t)SSD_MAX_LEVELS * B * sizeof(int));
+    return loss_ws_layout((size_t)B * A, nullptr, nullptr) + al256((size_t)SSD_MAX_LEVELS * B * sizeof(int)) +
+           al256((size_t)3 * SSD_MAX_LEVELS * B * sizeof(double));
 }
 
 int ssd_loss_fwd_bwd_heads(const void* conf, const void* loc, int dtype, const int32_t* gt_cls, const float* gt_loc,
                            const uint8_t* gt_mask, int B, int A, int C, float grad_scale, float* out8,
-                           const ssd_head_grads* hg, void* ws, size_t ws_bytes, void* stream) {
+                           const ssd_head_grads* hg, void* ws, size_t ws_bytes, int ws_clean, void* stream) {
     if (B <= 0 || A <= 0 || C < 2 || !hg) return SSD_ERR_VALUE;
     if (!conf || !loc || !gt_cls || !gt_loc || !gt_mask || !out8 || !hg->count) return SSD_ERR_VALUE;
     if (dtype != SSD_BF16) return SSD_ERR_UNSUPPORTED;
@@ -652,21 +703,24 @@ int ssd_loss_fwd_bwd_heads(const void* conf, const void* loc, int dtype, const i
     h.count = hg->count;
     const size_t n = (size_t)B * A;
     const size_t base = loss_ws_layout(n, nullptr, nullptr);
-    if (!ws || ws_bytes < base + al256((size_t)SSD_MAX_LEVELS * B * sizeof(int))) return SSD_ERR_WORKSPACE;
+    const size_t cnt_bytes = al256((size_t)SSD_MAX_LEVELS * B * sizeof(int));
+    if (!ws || ws_bytes < base + cnt_bytes + al256((size_t)3 * SSD_MAX_LEVELS * B * sizeof(double))) return SSD_ERR_WORKSPACE;
     LossWs w;
     loss_ws_layout(n, static_cast<char*>(ws), &w);
     h.img_count = reinterpret_cast<int*>(static_cast<char*>(ws) + base);
+    double* part_neg_il = reinterpret_cast<double*>(static_cast<char*>(ws) + base + cnt_bytes);
     hipStream_t s = (hipStream_t)stream;
     typedef __hip_bfloat16 T;
     const size_t nblk = (n + ROWS - 1) / ROWS;
     const size_t lds = ((size_t)ROWS * C * sizeof(float) + 15) / 16 * 16;
-    if (hipMemsetAsync(w.hist1, 0, w.zero_bytes, s) != hipSuccess) return SSD_ERR_LAUNCH;
+    // ws_clean: the caller states that the histogram words of THIS workspace layout are zero -- true after a completed call of
+    // this function with the same B, A (its last launch re-zeroes them) -- and the memset node is skipped
+    if (!ws_clean && hipMemsetAsync(w.hist1, 0, w.zero_bytes, s) != hipSuccess) return SSD_ERR_LAUNCH;
     launch_loss_select<T>(conf, loc, gt_cls, gt_loc, gt_mask, n, C, w, s, lds, false);
-    hipLaunchKernelGGL(k_hg_count, dim3(B, hg->levels), dim3(WG), 0, s, gt_mask, w, h);
-    hipLaunchKernelGGL(k_hg_assign, dim3(B, hg->levels), dim3(WG), 0, s, gt_mask, w, h);
+    hipLaunchKernelGGL(k_hg_count, dim3(B, hg->levels), dim3(WG), 0, s, gt_mask, w, h, part_neg_il, nblk);
+    hipLaunchKernelGGL(k_hg_assign, dim3(B, hg->levels), dim3(WG), 0, s, gt_mask, w, h, nblk, (const double*)part_neg_il, out8);
     hipLaunchKernelGGL(k_loss_grad_rows, dim3((unsigned)nblk), dim3(WG), 0, s, (const T*)conf, (const T*)loc, gt_cls, gt_loc,
                        gt_mask, n, C, grad_scale, w, h);
-    hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(WG), 0, s, nblk, w, out8);
     return ssd_launch_status();
 }
 

@@ -190,7 +190,9 @@ def ssd_loss(conf, loc, gt_cls, gt_loc, gt_mask, grad_scale=1.0, ws=None):
     dconf = torch.empty_like(conf)
     dloc = torch.empty_like(loc)
     nbytes = L.ssd_loss_workspace_bytes(B, A, C)
-    wbuf = (ws or _loss_ws).get(nbytes, conf.device)
+    wsobj = ws or _loss_ws
+    wbuf = wsobj.get(nbytes, conf.device)
+    wsobj.clean_key = None                         # (this form leaves the histogram words dirty: see ssd_loss_heads)
     _lib.check(L.ssd_loss_fwd_bwd(_ptr(conf), _ptr(loc), dtype, _ptr(gt_cls), _ptr(gt_loc), _ptr(gt_mask), B, A, C,
                                   float(grad_scale), _ptr(out), _ptr(dconf), _ptr(dloc), _ptr(wbuf), wbuf.numel(),
                                   _stream()))
@@ -244,10 +246,17 @@ def ssd_loss_heads(conf, loc, gt_cls, gt_loc, gt_mask, hgb, grad_scale=1.0, ws=N
     _dev(gt_cls, torch.int32); _dev(gt_loc, torch.float32); _dev(gt_mask, torch.uint8)
     out = torch.empty((8,), dtype=torch.float32, device=conf.device)
     nbytes = L.ssd_loss_heads_workspace_bytes(B, A, C)
-    wbuf = (ws or _loss_ws).get(nbytes, conf.device)
+    wsobj = ws or _loss_ws
+    wbuf = wsobj.get(nbytes, conf.device)
+    # ws_clean: a completed call leaves the histogram words of this layout zeroed (its last launch does it), so the next call on
+    # the same buffer, same B * A and same stream order needs no memset node; anything else in between resets the claim
+    key = (B * A, wbuf.data_ptr(), wbuf.numel())
+    clean = getattr(wsobj, "clean_key", None) == key
+    wsobj.clean_key = None
     _lib.check(L.ssd_loss_fwd_bwd_heads(_ptr(conf), _ptr(loc), 1, _ptr(gt_cls), _ptr(gt_loc), _ptr(gt_mask), B, A, C,
                                         float(grad_scale), _ptr(out), ctypes.byref(hgb.c), _ptr(wbuf), wbuf.numel(),
-                                        _stream()))
+                                        1 if clean else 0, _stream()))
+    wsobj.clean_key = key
     return out
 
 

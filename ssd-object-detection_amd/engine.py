@@ -118,6 +118,9 @@ class SSDEngine:
         # fused-optimizer buckets that run at the END of the main stream instead of in the side stream's queue: the side stream (weight
         # gradients) is the longer chain, the main stream finishes ~0.5 ms earlier (round 4, same-box A/B: 1 -> 4 buckets -0.06 ms)
         self.opt_defer = int(os.environ.get("SSD_OPT_DEFER", "4"))
+        # the heads' bucket (45 % of the parameters) is complete right after the loss, where the side stream would run its
+        # HBM-bound update next to the extras' latency-bound data-gradient chain: 1 = run it at the main stream's tail instead
+        self.opt_defer_heads = int(os.environ.get("SSD_OPT_DEFER_HEADS", "0"))
         self.pool_only = {}                    # node -> whether a pool-only kernel serves it (learned at the first call)
         self.fuse_unpool = {} if os.environ.get("SSD_FUSE_UNPOOL", "1") == "1" else None    # node -> data gradient un-pools itself
         # activation index -> its sign bits are written by the forward kernel (learned at the first call); data-gradient
@@ -488,7 +491,7 @@ class SSDEngine:
                 on_dgrad(node)
             if node in opt_at:
                 t0, t1 = opt_at.pop(node)
-                if side is not None and node is not None and node in defer_nodes:
+                if side is not None and ((node is not None and node in defer_nodes) or (node is None and self.opt_defer_heads)):
                     ev = torch.cuda.Event()
                     ev.record(side)                    # the bucket's weight gradients are all enqueued there by now
                     deferred.append((t0, t1, ev))

@@ -36,6 +36,7 @@ struct ZLevel {
 };
 struct ZArgs {
     int levels;
+    unsigned mask;                           // bit l: level l takes part in this launch
     ZLevel lv[SSD_MAX_LEVELS];
     const int* count;
 };
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(256) void k_hz_gemm(ZArgs a) {
 #pragma unroll
     for (int l = 0; l < SSD_MAX_LEVELS; ++l) {
         int t = 0;
-        if (l < a.levels) t = ((a.count[l] + ZT - 1) / ZT) * (a.lv[l].N / ZT);
+        if (l < a.levels && ((a.mask >> l) & 1u)) t = ((a.count[l] + ZT - 1) / ZT) * (a.lv[l].N / ZT);
         pre[l + 1] = pre[l] + t;
     }
     const int total = pre[SSD_MAX_LEVELS];
@@ -532,15 +533,18 @@ size_t ssd_heads_bwd_data_sparse_workspace_bytes(int B, const ssd_head_layers* h
     return tot;
 }
 
-int ssd_heads_bwd_data_sparse(const ssd_head_grads* hg, const ssd_head_layers* hl, int B, void* ws, size_t ws_bytes,
-                              void* stream) {
+int ssd_heads_bwd_data_sparse_levels(const ssd_head_grads* hg, const ssd_head_layers* hl, int B, unsigned level_mask, void* ws,
+                                     size_t ws_bytes, void* stream) {
     const int rc = check_heads(hg, hl, B);
     if (rc != SSD_OK) return rc;
     if (!ws || ws_bytes < ssd_heads_bwd_data_sparse_workspace_bytes(B, hl)) return SSD_ERR_WORKSPACE;
+    level_mask &= (1u << hg->levels) - 1u;
+    if (!level_mask) return SSD_ERR_VALUE;
     hipStream_t s = (hipStream_t)stream;
     ZArgs za;
     CArgs ca;
     za.levels = ca.levels = hg->levels;
+    za.mask = level_mask;
     za.count = hg->count;
     ca.B = B;
     char* p = static_cast<char*>(ws);
@@ -553,11 +557,12 @@ int ssd_heads_bwd_data_sparse(const ssd_head_grads* hg, const ssd_head_layers* h
         }
         if (!hl->w_tap[l] || !hl->dx[l]) return SSD_ERR_VALUE;
         const int hw = hg->hw[l], N = 9 * hl->Cin[l];
-        float* z = reinterpret_cast<float*>(p);
-        p += ssd_align_up((size_t)B * hw * N * sizeof(float), 256);
+        float* z = reinterpret_cast<float*>(p);                  // (every level keeps its own slice whatever the mask: two calls
+        p += ssd_align_up((size_t)B * hw * N * sizeof(float), 256);   //  with disjoint masks may share `ws` on two streams)
         za.lv[l] = ZLevel{(const bf16_raw*)hg->rows[l], (const bf16_raw*)hl->w_tap[l], z, hg->npad[l], N};
         ca.lv[l] = CLevel{z, hg->row_of_pixel[l], (const unsigned char*)hl->relu_bits[l], (const bf16_raw*)hl->relu_src[l],
                           (bf16_raw*)hl->dx[l], hl->H[l], hl->W[l], hl->Cin[l], blk};
+        if (!((level_mask >> l) & 1u)) continue;                 // no workgroups: the level lookup skips an empty range
         blk += (int)(((long long)((B * hw + C2I_PIX - 1) / C2I_PIX) * (hl->Cin[l] >> 3) + 255) / 256);
         cap_tiles += ((B * hw + ZT - 1) / ZT) * (N / ZT);
     }
@@ -565,6 +570,11 @@ int ssd_heads_bwd_data_sparse(const ssd_head_grads* hg, const ssd_head_layers* h
     hipLaunchKernelGGL(k_hz_gemm, dim3(min(cap_tiles, 2048)), dim3(256), 2 * ZBUF, s, za);
     hipLaunchKernelGGL(k_hz_col2im, dim3(blk), dim3(256), 0, s, ca);
     return ssd_launch_status();
+}
+
+int ssd_heads_bwd_data_sparse(const ssd_head_grads* hg, const ssd_head_layers* hl, int B, void* ws, size_t ws_bytes,
+                              void* stream) {
+    return ssd_heads_bwd_data_sparse_levels(hg, hl, B, ~0u, ws, ws_bytes, stream);
 }
 
 size_t ssd_heads_bwd_weight_sparse_workspace_bytes(int B, const ssd_head_grads* hg, const ssd_head_layers* hl) {

@@ -115,6 +115,7 @@ class SSDEngine:
         self.tail_stream = os.environ.get("SSD_TAIL_STREAM", "1") == "1"
         self.big_heads_side = os.environ.get("SSD_BIG_HEADS_SIDE", "1") == "1"
         self.pack_side = os.environ.get("SSD_PACK_SIDE", "1") == "1"
+        self.split_heads_dgrad = os.environ.get("SSD_SPLIT_HEADS_DGRAD", "1") == "1"
         # fused-optimizer buckets that run at the END of the main stream instead of in the side stream's queue: the side stream (weight
         # gradients) is the longer chain, the main stream finishes ~0.5 ms earlier (round 4, same-box A/B: 1 -> 4 buckets -0.06 ms)
         self.opt_defer = int(os.environ.get("SSD_OPT_DEFER", "4"))
@@ -517,13 +518,34 @@ class SSDEngine:
         # that the main stream can walk the small levels and the extras' data-gradient chain (a dozen launches that
         # each fill a fraction of the chip) underneath them.  The accumulation order into a feature-map gradient is
         # still "head first, trunk second": the trunk launch waits for the head's event.
+        sparse_head_done = {}                              # activation index -> event after a large level's sparse data gradient
         if heads is not None:
             # all levels at once from the compact rows: data gradient on the main stream (every feature-map gradient is
             # written before the trunk chain accumulates into it), weight gradient next to it on the side stream
             hl, keep = self._head_layers(c)
             on_side(lambda ws: ops.heads_bwd_weight_sparse(heads, hl, ws=self._ws_hw),
                     [i for wt, bt in self.head_params for t in (wt, bt) for i in t.indices])
-            ops.heads_bwd_data_sparse(heads, hl, ws=self._ws_hz)
+            big_lv = [lvl for lvl, (ni, h, ch) in enumerate(self.fm) if B * h * h >= 16384]
+            small_lv = [lvl for lvl in range(len(self.fm)) if lvl not in big_lv]
+            if side is not None and self.split_heads_dgrad and big_lv and small_lv:
+                # the small maps' gradients head the extras' chain; the 38x38 / 19x19 maps' (most of the launch's time: their
+                # dense maps are ~140 MB of stores) are not read until the chain reaches those maps -- third stream, the
+                # chain's accumulation waits for its event (sparse_head_done)
+                ops.heads_bwd_data_sparse(heads, hl, ws=self._ws_hz, levels=small_lv)
+                if getattr(self, "_tail", None) is None:
+                    self._tail = torch.cuda.Stream(device=self.device)
+                    self._ws_tail = ops.MatchWorkspace()
+                ev = torch.cuda.Event()
+                ev.record(main)
+                with torch.cuda.stream(self._tail):
+                    self._tail.wait_event(ev)
+                    ops.heads_bwd_data_sparse(heads, hl, ws=self._ws_hz, levels=big_lv)
+                    done = torch.cuda.Event()
+                    done.record(self._tail)
+                for lvl in big_lv:
+                    sparse_head_done[self.fm[lvl][0] + 1] = done
+            else:
+                ops.heads_bwd_data_sparse(heads, hl, ws=self._ws_hz)
             for ni, _, _ in self.fm:
                 written[ni + 1] = True
             del keep
@@ -638,6 +660,8 @@ class SSDEngine:
             prev_is_relu_conv = self.nodes[i - 1]["kind"] == "conv"
             if i in head_done:                    # a large head wrote gacts[i] on the side stream: accumulate after it
                 main.wait_event(head_done.pop(i))
+            if i in sparse_head_done:
+                main.wait_event(sparse_head_done.pop(i))
             # a 3x3 / stride-1 convolution right behind a pooling: its data gradient is carried through the pooling in the
             # convolution's own store stage (no pooled gradient in HBM, no pooling-backward launch) where an LDS-patch kernel
             # serves the layer; learned at the first call, like pool_only
@@ -660,6 +684,8 @@ class SSDEngine:
             written[i] = True
             opt_bucket(i)
         assert not opt_at
+        for ev in sparse_head_done.values():      # (a large level whose map no trunk node accumulated into)
+            main.wait_event(ev)
         for t0, t1, ev in deferred:
             main.wait_event(ev)
             self.adam_range(t0, t1, lr_t, hp["beta1"], hp["beta2"], hp["eps"], hp["clip"])

@@ -285,11 +285,20 @@ _heads_z_ws = MatchWorkspace()
 _heads_w_ws = MatchWorkspace()
 
 
-def heads_bwd_data_sparse(hgb, hl, ws=None):
+def heads_bwd_data_sparse(hgb, hl, ws=None, levels=None):
+    """levels: None = every level, else the levels of this call (ssd_heads_bwd_data_sparse_levels; calls with disjoint sets may
+    share `ws` on two streams)."""
     L = _lib.lib()
     nbytes = L.ssd_heads_bwd_data_sparse_workspace_bytes(hgb.B, ctypes.byref(hl))
     wbuf = (ws or _heads_z_ws).get(nbytes, hgb.count.device)
-    _lib.check(L.ssd_heads_bwd_data_sparse(ctypes.byref(hgb.c), ctypes.byref(hl), hgb.B, _ptr(wbuf), wbuf.numel(), _stream()))
+    if levels is None:
+        _lib.check(L.ssd_heads_bwd_data_sparse(ctypes.byref(hgb.c), ctypes.byref(hl), hgb.B, _ptr(wbuf), wbuf.numel(), _stream()))
+        return
+    mask = 0
+    for l in levels:
+        mask |= 1 << int(l)
+    _lib.check(L.ssd_heads_bwd_data_sparse_levels(ctypes.byref(hgb.c), ctypes.byref(hl), hgb.B, mask, _ptr(wbuf), wbuf.numel(),
+                                                  _stream()))
 
 
 def heads_bwd_weight_sparse(hgb, hl, ws=None):

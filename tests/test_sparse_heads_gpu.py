@@ -112,7 +112,7 @@ def head_oracle(x, w, rows_dense):
     return xr.grad.permute(0, 2, 3, 1), wr.grad.permute(0, 2, 3, 1), br.grad
 
 
-def run_heads(ops, B, conf, loc, targets, seed=0, levels=range(6), check_oracle=(0, 1, 2, 3, 4, 5), use_bits=True):
+def run_heads(ops, B, conf, loc, targets, seed=0, levels=range(6), check_oracle=(0, 1, 2, 3, 4, 5), use_bits=True, split=None):
     cls, gloc, mask = targets
     hgb = ops.HeadGradBuffers(B, HW, NPC, NPAD)
     ops.ssd_loss_heads(conf, loc, cls, gloc, mask, hgb)
@@ -131,7 +131,15 @@ def run_heads(ops, B, conf, loc, targets, seed=0, levels=range(6), check_oracle=
         bits.append((b8 * (2 ** torch.arange(8, device="cuda", dtype=torch.uint8))).sum(-1).to(torch.uint8).contiguous())
     hl, keep = ops.head_layers(xs, wts, dxs, dws, dbs, [n * 85 for n in NPC],
                                relu_bits=bits if use_bits else None, relu_src=None if use_bits else xs)
-    ops.heads_bwd_data_sparse(hgb, hl)
+    if split is None:
+        ops.heads_bwd_data_sparse(hgb, hl)
+    else:                                                   # two calls with complementary level sets on two streams, one workspace
+        other = torch.cuda.Stream()
+        other.wait_stream(torch.cuda.current_stream())
+        ops.heads_bwd_data_sparse(hgb, hl, levels=[l for l in range(6) if l not in split])
+        with torch.cuda.stream(other):
+            ops.heads_bwd_data_sparse(hgb, hl, levels=split)
+        torch.cuda.current_stream().wait_stream(other)
     ops.heads_bwd_weight_sparse(hgb, hl)
     torch.cuda.synchronize()
     sl, sc = hgb.dense(81)
@@ -187,6 +195,21 @@ def test_heads_backward_vs_dense_kernels_batch16(ops):
         assert (a - b).abs().max() <= 2.0 ** -7 * b.abs().max()        # each is one bf16 rounding away from the fp32 sum
         assert (dws[l] - ddw).abs().max() <= 1e-3 * ddw.abs().max()
         assert (dbs[l] - ddb).abs().max() <= 1e-3 * ddb.abs().max()
+
+
+def test_level_subsets_equal_the_whole_call(ops):
+    """ssd_heads_bwd_data_sparse_levels: the large levels on a second stream (the engine's schedule at batch 64) write the
+    same bits as the one call; an empty set is a value error."""
+    B = 4
+    targets = make_targets(ops, B, first=40)
+    conf, loc = logits(B, 25)
+    whole = run_heads(ops, B, conf, loc, targets, check_oracle=())
+    for split in ([0, 1], [2, 3, 4, 5], [0, 5]):
+        parts = run_heads(ops, B, conf, loc, targets, check_oracle=(), split=split)
+        for l in range(6):
+            assert torch.equal(whole[1][l].view(torch.int16), parts[1][l].view(torch.int16)), (split, l)
+    with pytest.raises(ValueError):
+        run_heads(ops, B, conf, loc, targets, check_oracle=(), split=[0, 1, 2, 3, 4, 5])
 
 
 def test_every_anchor_selected(ops):

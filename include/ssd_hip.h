@@ -326,6 +326,28 @@ int ssd_maxpool2x2_bwd_argmax(const void* code, const void* dy, void* dx, int B,
 int ssd_quantize_mx_fp8(const void* x_bf16, void* q, void* scale, long long n, void* stream);
 int ssd_conv3x3_fwd_mxfp8(const void* x8, const void* xscale, const void* w8, const void* wscale, const float* bias, void* y, int B,
                           int H, int W, int Cin, int Cout, int relu, void* stream);
+/* A chain of small convolutions in ONE launch, one workgroup per image, activations in LDS (chain.hip) -- the reference's
+ * "extras" behind the 19x19 map (models/ssd_model.py:124-150: six layers on 10x10 ... 1x1 maps), forward or data gradient.
+ * Layer l reads the output of layer l-1 (layer 0: in0 [B][Hi*Wi][Kc] bf16) and writes out [B][Ho*Wo][N] bf16:
+ *   out[o][n] = epilogue( sum over taps t, channels k of  in[(o * mul + t - pad) / div][k] * w[n][t][k] )
+ * with the source pixel taken only when divisible by div and inside the map -- the implicit-GEMM geometry of
+ * ssd_conv2d_fwd (mul = stride, div = 1, w = filters [Cout][k][k][Cin]) and of ssd_conv2d_bwd_data (mul = 1, div = stride,
+ * pad = ksize - 1 - pad, w = ssd_weight_transpose's [Cin][k][k][Cout_pad]).  Epilogue: + bias (if not null), ReLU (relu != 0),
+ * sign bits written to relu_bits (if not null); accumulate != 0: out += result BEFORE the mask (two gradients meet at a
+ * feature map); mask_bits / mask_src (at most one): zero where the bit is clear / the value is <= 0.
+ * Needs Kc % 128 == 0, N % 16 == 0, Ho*Wo <= 112, div in {1, 2}, every layer's input + output image within 160 KB of LDS
+ * (rows padded by 16 bytes): SSD_ERR_UNSUPPORTED otherwise, nothing launched.  fp32 accumulation in one pass over k. */
+#define SSD_CHAIN_MAX_LAYERS 8
+typedef struct {
+    const void* w;
+    const float* bias;
+    void* out;
+    const void* mask_bits;
+    const void* mask_src;
+    void* relu_bits;
+    int Hi, Wi, Kc, Ho, Wo, N, ksize, mul, div, pad_t, pad_l, relu, accumulate;
+} ssd_chain_layer;
+int ssd_conv_chain(const void* in0, const ssd_chain_layer* layers, int nlayers, int B, void* stream);
 /* Pieces of a ResNet-50 trunk (BASELINE configs[4]; the reference hard-codes its VGG trunk, models/ssd_model.py:46,75-97, so these
  * have no reference counterpart: semantics are Keras / TensorFlow's Add + ReLU, MaxPooling2D(3, strides=2, padding="same") and
  * their tape.gradient).  bf16 NHWC, n = element count (a multiple of 8).

@@ -50,6 +50,14 @@ class HeadLayers(ctypes.Structure):
                 ("dbias", VP * SSD_MAX_LEVELS)]
 
 
+class ChainLayer(ctypes.Structure):
+    """ssd_chain_layer: one convolution of ssd_conv_chain."""
+    _fields_ = [("w", VP), ("bias", VP), ("out", VP), ("mask_bits", VP), ("mask_src", VP), ("relu_bits", VP)] + \
+               [(n, ctypes.c_int) for n in ("Hi", "Wi", "Kc", "Ho", "Wo", "N", "ksize", "mul", "div", "pad_t", "pad_l", "relu",
+                                            "accumulate")]
+
+
+SSD_CHAIN_MAX_LAYERS = 8
 _HG = ctypes.POINTER(HeadGrads)
 _HL = ctypes.POINTER(HeadLayers)
 
@@ -78,6 +86,7 @@ _SIGNATURES = {
     "ssd_conv2d_bwd_data_unpool": (ctypes.c_int, [VP] * 6 + [ctypes.c_int] * 7 + [VP, ctypes.c_size_t, VP]),
     "ssd_quantize_mx_fp8": (ctypes.c_int, [VP, VP, VP, ctypes.c_longlong, VP]),
     "ssd_conv3x3_fwd_mxfp8": (ctypes.c_int, [VP] * 6 + [ctypes.c_int] * 6 + [VP]),
+    "ssd_conv_chain": (ctypes.c_int, [VP, ctypes.POINTER(ChainLayer), ctypes.c_int, ctypes.c_int, VP]),
     "ssd_add_relu_fwd": (ctypes.c_int, [VP, VP, VP, ctypes.c_longlong, VP]),
     "ssd_relu_mask_bwd": (ctypes.c_int, [VP, VP, VP, ctypes.c_int, ctypes.c_longlong, VP]),
     "ssd_maxpool3x3s2_fwd": (ctypes.c_int, [VP, VP, VP] + [ctypes.c_int] * 8 + [VP]),

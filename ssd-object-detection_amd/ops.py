@@ -469,6 +469,44 @@ def conv2d_bwd_data(dy, w_t, relu_src, x_shape, stride, pad_t, pad_l, accumulate
     return out
 
 
+def chain_layer_fwd(w, bias, out, stride, pad_t, pad_l, relu=True, relu_bits=None):
+    """One forward convolution of conv_chain: w bf16 [Cout,k,k,Cin], out bf16 [B,Ho,Wo,Cout]."""
+    return dict(w=w, bias=bias, out=out, ksize=w.shape[1], mul=stride, div=1, pad_t=pad_t, pad_l=pad_l, relu=relu,
+                relu_bits=relu_bits, Kc=w.shape[3], N=w.shape[0])
+
+
+def chain_layer_dgrad(w_t, out, stride, pad_t, pad_l, accumulate=False, mask_bits=None, mask_src=None):
+    """One data gradient of conv_chain: w_t bf16 [Cin,k,k,Cout_pad] (weight_transpose), out bf16 [B,H,W,Cin] = the gradient w.r.t.
+    the convolution's input (accumulated onto when `accumulate`), masked by the input activation's ReLU sign."""
+    k = w_t.shape[1]
+    return dict(w=w_t, bias=None, out=out, ksize=k, mul=1, div=stride, pad_t=k - 1 - pad_t, pad_l=k - 1 - pad_l, relu=False,
+                accumulate=accumulate, mask_bits=mask_bits, mask_src=mask_src, Kc=w_t.shape[3], N=w_t.shape[0])
+
+
+def conv_chain(in0, layers):
+    """ssd_conv_chain: layers (chain_layer_fwd / chain_layer_dgrad dicts) applied one after the other to in0 bf16 [B,H,W,C], one
+    workgroup per image, in one launch; every layer's `out` is written.  NotImplementedError (SSD_ERR_UNSUPPORTED, nothing
+    launched) where a layer does not fit the kernel."""
+    L = _lib.lib()
+    _bf(in0)
+    B, Hi, Wi, Kc = in0.shape
+    arr = (_lib.ChainLayer * len(layers))()
+    for d, s in zip(arr, layers):
+        out = s["out"]
+        _bf(s["w"]); _bf(out)
+        assert out.shape[0] == B and out.shape[3] == s["N"] and s["Kc"] == Kc, (tuple(out.shape), s["N"], s["Kc"], Kc)
+        d.w, d.bias, d.out = _ptr(s["w"]), _ptr(s.get("bias")), _ptr(out)
+        d.mask_bits, d.mask_src, d.relu_bits = _ptr(s.get("mask_bits")), _ptr(s.get("mask_src")), _ptr(s.get("relu_bits"))
+        d.Hi, d.Wi, d.Kc, d.Ho, d.Wo, d.N = Hi, Wi, Kc, out.shape[1], out.shape[2], s["N"]
+        d.ksize, d.mul, d.div, d.pad_t, d.pad_l = s["ksize"], s["mul"], s["div"], s["pad_t"], s["pad_l"]
+        d.relu, d.accumulate = int(bool(s.get("relu"))), int(bool(s.get("accumulate")))
+        Hi, Wi, Kc = out.shape[1], out.shape[2], s["N"]
+    rc = L.ssd_conv_chain(_ptr(in0), arr, len(layers), B, _stream())
+    if rc == _lib.SSD_ERR_UNSUPPORTED:
+        raise NotImplementedError("ssd_conv_chain does not serve these layers")
+    _lib.check(rc)
+
+
 def conv2d_fwd_relubits(x, w, bias, stride, pad_t, pad_l, Ho, Wo, bits, out=None, ws=None):
     """conv2d_fwd with ReLU that also writes the sign bits of its output (uint8 [B,Ho,Wo,Cout/8]).  NotImplementedError
     (SSD_ERR_UNSUPPORTED, nothing launched) where the layer's kernel has no staged store."""

@@ -338,6 +338,18 @@ int ssd_conv3x3_fwd_mxfp8(const void* x8, const void* xscale, const void* w8, co
  * Needs Kc % 128 == 0, N % 16 == 0, Ho*Wo <= 112, div in {1, 2}, every layer's input + output image within 160 KB of LDS
  * (rows padded by 16 bytes): SSD_ERR_UNSUPPORTED otherwise, nothing launched.  fp32 accumulation in one pass over k. */
 #define SSD_CHAIN_MAX_LAYERS 8
+#define SSD_CHAIN_PACK_MAX 16
+/* w of a chain layer is NOT the filter tensor itself but its fragment-packed copy (ssd_chain_pack_weights): for filters
+ * [N][K] bf16 with k = (tap, channel) contiguous -- the forward filters [Cout][k*k*Cin] or ssd_weight_transpose's
+ * [Cin][k*k*Cout_pad] -- packed[N/16][K/32][64][8] with element (lane, e) of fragment (nt, s) = w[16 nt + (lane & 15)]
+ * [32 s + 8 (lane >> 4) + e]: a wave's MFMA operand is one contiguous KB.  N % 16 == 0, K % 32 == 0; up to
+ * SSD_CHAIN_PACK_MAX tensors per launch.  Re-pack after every optimizer step. */
+typedef struct {
+    const void* src;
+    void* dst;
+    int N, K;
+} ssd_chain_pack;
+int ssd_chain_pack_weights(const ssd_chain_pack* items, int count, void* stream);
 typedef struct {
     const void* w;
     const float* bias;

@@ -57,7 +57,13 @@ class ChainLayer(ctypes.Structure):
                                             "accumulate")]
 
 
+class ChainPack(ctypes.Structure):
+    """ssd_chain_pack: one filter tensor of ssd_chain_pack_weights."""
+    _fields_ = [("src", VP), ("dst", VP), ("N", ctypes.c_int), ("K", ctypes.c_int)]
+
+
 SSD_CHAIN_MAX_LAYERS = 8
+SSD_CHAIN_PACK_MAX = 16
 _HG = ctypes.POINTER(HeadGrads)
 _HL = ctypes.POINTER(HeadLayers)
 
@@ -86,6 +92,7 @@ _SIGNATURES = {
     "ssd_conv2d_bwd_data_unpool": (ctypes.c_int, [VP] * 6 + [ctypes.c_int] * 7 + [VP, ctypes.c_size_t, VP]),
     "ssd_quantize_mx_fp8": (ctypes.c_int, [VP, VP, VP, ctypes.c_longlong, VP]),
     "ssd_conv3x3_fwd_mxfp8": (ctypes.c_int, [VP] * 6 + [ctypes.c_int] * 6 + [VP]),
+    "ssd_chain_pack_weights": (ctypes.c_int, [ctypes.POINTER(ChainPack), ctypes.c_int, VP]),
     "ssd_conv_chain": (ctypes.c_int, [VP, ctypes.POINTER(ChainLayer), ctypes.c_int, ctypes.c_int, VP]),
     "ssd_add_relu_fwd": (ctypes.c_int, [VP, VP, VP, ctypes.c_longlong, VP]),
     "ssd_relu_mask_bwd": (ctypes.c_int, [VP, VP, VP, ctypes.c_int, ctypes.c_longlong, VP]),

@@ -32,7 +32,7 @@ constexpr int CH_MAX_MT = 7;                 // <= 112 output pixels per image a
 constexpr int CH_LDS_MAX = 160 * 1024;
 
 struct ChainLayer {
-    const bf16_raw* w;                       // [N][KH*KW][Kc]
+    const bf16_raw* w;                       // packed by ssd_chain_pack_weights: [N/16][KH*KW*Kc/32][64 lanes][8]
     const float* bias;                       // [N] or null
     bf16_raw* out;                           // [B][Ho*Wo][N]
     const unsigned char* mask_bits;          // [B][Ho*Wo][N/8] or null    (data gradient: ReLU sign bits of the layer's input activation)
@@ -59,36 +59,43 @@ __device__ __forceinline__ void chain_layer(const ChainLayer& L, char* smem, int
     const int in_stride = L.Kc * 2 + 16, out_stride = L.N * 2 + 16;
     const int div_mask = (1 << L.dshift) - 1;
     int by[MT], bx[MT];
+    {
+        const int Wo = L.Wo, mul = L.mul, pad_t = L.pad_t, pad_l = L.pad_l;
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
-        const int p = t * 16 + li;
-        const int oy = p / L.Wo, ox = p - oy * L.Wo;
-        by[t] = p < npix ? oy * L.mul - L.pad_t : -(1 << 20);      // (a row beyond the image never finds a source pixel)
-        bx[t] = ox * L.mul - L.pad_l;
+        for (int t = 0; t < MT; ++t) {
+            const int p = t * 16 + li;
+            const int oy = p / Wo, ox = p - oy * Wo;
+            by[t] = p < npix ? oy * mul - pad_t : -(1 << 20);      // (a row beyond the image never finds a source pixel)
+            bx[t] = ox * mul - pad_l;
+        }
     }
     const int ntiles = L.N >> 4;
     // byte offset of the source pixel's LDS row for the current tap; a tap without a source pixel (padding, a stride-2 gap,
     // a row beyond the image) reads the zero row instead: no select behind the LDS read
     int poff[MT];
+    // (the layer record lives in kernel-argument memory: every field the loops use is copied to a scalar ONCE -- read through
+    //  the reference, each use was an s_load + s_waitcnt of its own, 2-3 us per tap)
+    const int Hi = L.Hi, Wi = L.Wi, dshift = L.dshift, in_off = L.in_off, KW = L.KW;
     auto set_tap = [&](int kh, int kw) {
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             const int iy = by[t] + kh, ix = bx[t] + kw;
-            const int sy = iy >> L.dshift, sx = ix >> L.dshift;
-            const bool ok = iy >= 0 && ix >= 0 && ((iy | ix) & div_mask) == 0 && sy < L.Hi && sx < L.Wi;
-            const int pix = ok ? sy * L.Wi + sx : 0;
-            poff[t] = ok ? L.in_off + pix * in_stride : zero_off;
+            const int sy = iy >> dshift, sx = ix >> dshift;
+            const bool ok = ((iy | ix) >= 0) & (((iy | ix) & div_mask) == 0) & (sy < Hi) & (sx < Wi);
+            poff[t] = ok ? in_off + (sy * Wi + sx) * in_stride : zero_off;
         }
     };
     // k runs in groups of four 32-channel steps (Kc % 128 == 0: a group never straddles a tap); the filter ring holds CH_D / 4
-    // groups, group g lives in ring quarter g % (CH_D / 4): static register indices with a loop body of CH_D steps
-    const int G = S >> 2, gpt = kpt >> 2;
+    // groups, group g lives in ring quarter g % (CH_D / 4): static register indices with a loop body of CH_D steps.  The body has
+    // NO conditional loads (the compiler's vmcnt bookkeeping gives up at a branch and waits for every load in flight -- measured:
+    // one full memory latency per group, 141 us for the six layers): the group count is padded to a multiple of four, a padding
+    // group multiplies (valid, clamped) filter words with the zero row.
+    const int G = S >> 2, gpt = kpt >> 2, Gp = (G + CH_D / 4 - 1) & ~(CH_D / 4 - 1);
     for (int nt = wave; nt < ntiles; nt += CH_THREADS / 64) {
-        const bf16_raw* wrow = L.w + (long long)(nt * 16 + li) * taps * L.Kc + gq * 8;
+        const bf16_raw* wrow = L.w + ((long long)nt * S * 64 + lane) * 8;      // fragment (nt, s): 1 KB contiguous, lane-major
         bf16x8_t ring[CH_D];
 #pragma unroll
-        for (int d = 0; d < CH_D; ++d)
-            if ((d >> 2) < G) ring[d] = ld_frag(wrow + d * 32);
+        for (int d = 0; d < CH_D; ++d) ring[d] = ld_frag(wrow + min(d, S - 1) * 512);
         f32x4_t acc[MT];
 #pragma unroll
         for (int t = 0; t < MT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -107,21 +114,24 @@ __device__ __forceinline__ void chain_layer(const ChainLayer& L, char* smem, int
                 for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[R0 + j], f[t], acc[t], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (g + CH_D / 4 < G) {                              // refill the quarter: CH_D - 4 steps ahead of its use
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ring[R0 + j] = ld_frag(wrow + ((g + CH_D / 4) * 4 + j) * 32);
-            }
-            if (++gk == gpt) {
+            for (int j = 0; j < 4; ++j)                          // refill the quarter: CH_D - 4 steps ahead of its use
+                ring[R0 + j] = ld_frag(wrow + min((g + CH_D / 4) * 4 + j, S - 1) * 512);
+            if (g + 1 >= G) {                                    // behind the last group: zeros
+#pragma unroll
+                for (int t = 0; t < MT; ++t) poff[t] = zero_off;
                 gk = 0;
-                if (++kw == L.KW) { kw = 0; ++kh; }
+            } else if (++gk == gpt) {
+                gk = 0;
+                if (++kw == KW) { kw = 0; ++kh; }
                 set_tap(kh, kw);
             }
         };
-        for (int g0 = 0; g0 < G; g0 += CH_D / 4) {
+        for (int g0 = 0; g0 < Gp; g0 += CH_D / 4) {
             group(g0, std::integral_constant<int, 0>{});
-            if (g0 + 1 < G) group(g0 + 1, std::integral_constant<int, 4>{});
-            if (g0 + 2 < G) group(g0 + 2, std::integral_constant<int, 8>{});
-            if (g0 + 3 < G) group(g0 + 3, std::integral_constant<int, 12>{});
+            group(g0 + 1, std::integral_constant<int, 4>{});
+            group(g0 + 2, std::integral_constant<int, 8>{});
+            group(g0 + 3, std::integral_constant<int, 12>{});
         }
         // lane: channels n..n+3 of pixel 16 t + li
         const int n = nt * 16 + gq * 4;
@@ -183,9 +193,21 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(ChainArgs a) {
         const int cpr = L0.Kc >> 3, stride = L0.Kc * 2 + 16;         // 16-byte chunks per pixel row
         const int total = L0.Hi * L0.Wi * cpr;
         const uint4* src = reinterpret_cast<const uint4*>(a.in0 + (long long)b * L0.Hi * L0.Wi * L0.Kc);
-        for (int i = threadIdx.x; i < total; i += CH_THREADS) {
-            const int r = i / cpr, c = i - r * cpr;
-            *reinterpret_cast<uint4*>(smem + L0.in_off + r * stride + c * 16) = src[i];
+        for (int i0 = threadIdx.x; i0 < total; i0 += 4 * CH_THREADS) {   // four loads in flight per thread
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * CH_THREADS;
+                v[u] = i < total ? src[i] : make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * CH_THREADS;
+                if (i < total) {
+                    const int r = i / cpr, c = i - r * cpr;
+                    *reinterpret_cast<uint4*>(smem + L0.in_off + r * stride + c * 16) = v[u];
+                }
+            }
         }
     }
     for (int l = 0; l < a.nlayers; ++l) {
@@ -199,11 +221,46 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(ChainArgs a) {
     }
 }
 
+// Filters [N][K] (k contiguous: forward [Cout][kh*kw*Cin], data gradient [Cin][kh*kw*Cout_pad]) -> the MFMA A fragments
+// k_conv_chain loads: [N/16][K/32][64 lanes][8], fragment (nt, s), lane (li, gq) = w[16 nt + li][32 s + 8 gq .. + 7].  A wave's
+// load of a fragment is then ONE contiguous KB: read in place, the 16 rows of a fragment are 64-byte pieces of 16 lines and the
+// CU's texture-address path delivered 16 B/clk (measured: ~540 cycles per k-step whatever the LDS / MFMA work was).
+struct PackItem { const bf16_raw* src; bf16_raw* dst; int N, K; };
+struct PackArgs { PackItem it[SSD_CHAIN_PACK_MAX]; };
+__global__ __launch_bounds__(256) void k_chain_pack(PackArgs a) {
+    const PackItem it = a.it[blockIdx.y];
+    const int S = it.K >> 5;
+    const long long total = (long long)(it.N >> 4) * S * 64;          // 16-byte pieces
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int lane = (int)(i & 63);
+        const long long f = i >> 6;
+        const int s = (int)(f % S), nt = (int)(f / S);
+        const uint4 v = *reinterpret_cast<const uint4*>(it.src + (long long)(nt * 16 + (lane & 15)) * it.K + s * 32 + (lane >> 4) * 8);
+        *reinterpret_cast<uint4*>(it.dst + i * 8) = v;
+    }
+}
+
 std::atomic<int> g_lds_set{0};
 
 }  // namespace
 
 extern "C" {
+
+int ssd_chain_pack_weights(const ssd_chain_pack* items, int count, void* stream) {
+    if (!items || count <= 0 || count > SSD_CHAIN_PACK_MAX) return SSD_ERR_VALUE;
+    PackArgs a;
+    long long most = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!items[i].src || !items[i].dst || items[i].N <= 0 || items[i].K <= 0 || (items[i].N & 15) || (items[i].K & 31)) return SSD_ERR_VALUE;
+        a.it[i] = PackItem{static_cast<const bf16_raw*>(items[i].src), static_cast<bf16_raw*>(items[i].dst), items[i].N, items[i].K};
+        const long long pieces = (long long)items[i].N * items[i].K / 8;
+        most = pieces > most ? pieces : most;
+    }
+    for (int i = count; i < SSD_CHAIN_PACK_MAX; ++i) a.it[i] = a.it[0];
+    const unsigned gx = (unsigned)((most + 255) / 256 < 256 ? (most + 255) / 256 : 256);
+    hipLaunchKernelGGL(k_chain_pack, dim3(gx, count), dim3(256), 0, (hipStream_t)stream, a);
+    return ssd_launch_status();
+}
 
 int ssd_conv_chain(const void* in0, const ssd_chain_layer* layers, int nlayers, int B, void* stream) {
     if (!in0 || !layers || nlayers <= 0 || nlayers > SSD_CHAIN_MAX_LAYERS || B <= 0) return SSD_ERR_VALUE;

@@ -98,6 +98,9 @@ class SSDEngine:
         # the heads' backward pass from the loss's compact gradient rows (csrc/sparse.hip); SSD_SPARSE_HEADS=0: the dense
         # kernels on the scattered gradient (tests compare the two)
         self.sparse_heads = (os.environ.get("SSD_SPARSE_HEADS", "1") == "1") if sparse_heads is None else bool(sparse_heads)
+        # the trailing convolutions on LDS-sized maps (the extras behind the 19x19 map) as ONE launch, forward and data gradient
+        # (ops.conv_chain); a set: {"fwd", "bwd"}, emptied by a refusal of the kernel
+        self.chain = {"1": {"fwd", "bwd"}, "fwd": {"fwd"}, "bwd": {"bwd"}}.get(os.environ.get("SSD_CHAIN", "1"), set())
         self._plan_shapes()
         self._plan_params()
         self._alloc_params()
@@ -115,7 +118,10 @@ class SSDEngine:
         self.tail_stream = os.environ.get("SSD_TAIL_STREAM", "1") == "1"
         self.big_heads_side = os.environ.get("SSD_BIG_HEADS_SIDE", "1") == "1"
         self.pack_side = os.environ.get("SSD_PACK_SIDE", "1") == "1"
-        self.split_heads_dgrad = os.environ.get("SSD_SPLIT_HEADS_DGRAD", "1") == "1"
+        self.split_heads_dgrad = int(os.environ.get("SSD_SPLIT_HEADS_DGRAD", "2"))   # 0 one call, 1 small | large levels, 2 ... and one call per large level
+        # the heads of the maps the forward chain produces (all available at once, behind one launch): every other one on the
+        # main stream instead of queueing all of them on the third
+        self.chain_heads_split = os.environ.get("SSD_CHAIN_HEADS_SPLIT", "1") == "1"
         # fused-optimizer buckets that run at the END of the main stream instead of in the side stream's queue: the side stream (weight
         # gradients) is the longer chain, the main stream finishes ~0.5 ms earlier (round 4, same-box A/B: 1 -> 4 buckets -0.06 ms)
         self.opt_defer = int(os.environ.get("SSD_OPT_DEFER", "4"))
@@ -149,6 +155,14 @@ class SSDEngine:
             if feat:
                 self.fm.append((len(self.nodes) - 1, ho, cout))
         assert len(self.fm) == len(self.num_priors)
+        # the chain: the longest run of trailing convolutions whose input and output maps have <= 112 pixels and whose channel
+        # counts are multiples of 128 (ssd_conv_chain's limits), each behind another convolution (its ReLU is the mask)
+        j = len(self.nodes)
+        while (j > 1 and len(self.nodes) - j < _lib.SSD_CHAIN_MAX_LAYERS and self.nodes[j - 1]["kind"] == "conv"
+               and self.nodes[j - 2]["kind"] == "conv" and self.nodes[j - 1]["hin"] ** 2 <= 112 and self.nodes[j - 1]["hout"] ** 2 <= 112
+               and self.nodes[j - 1]["cin"] % 128 == 0 and self.nodes[j - 1]["cout"] % 128 == 0):
+            j -= 1
+        self.chain_start = j if len(self.nodes) - j >= 2 else None
         if any(c % 128 for _, _, c in self.fm) or len(self.fm) > _lib.SSD_MAX_LEVELS:
             self.sparse_heads = False
         self.level_off = [0]
@@ -218,6 +232,13 @@ class SSDEngine:
         for i, nd in enumerate(self.nodes):
             if nd["kind"] == "conv" and i > 0:
                 self.w_t[i] = torch.empty((nd["cin"], nd["k"], nd["k"], nd["cout"]), dtype=torch.bfloat16, device=dev)
+        # fragment-packed copies of the chain layers' filters (ops.conv_chain's operands), forward and data gradient
+        self.chain_pk_fwd, self.chain_pk_bwd = {}, {}
+        if getattr(self, "chain_start", None) is not None and self.chain:
+            for i in range(self.chain_start, len(self.nodes)):
+                nd = self.nodes[i]
+                self.chain_pk_fwd[i] = torch.empty((nd["cout"], nd["k"], nd["k"], nd["cin"]), dtype=torch.bfloat16, device=dev)
+                self.chain_pk_bwd[i] = torch.empty_like(self.w_t[i])
         self.head_npad = [(n * (4 + self.classes) + 7) // 8 * 8 for n in self.num_priors]
         # transposed head filters: [Cin][3][3][npad] flipped for the dense data gradient, or tap-major [3][3][Cin][npad] for
         # the sparse one
@@ -281,6 +302,14 @@ class SSDEngine:
             assert inside == list(range(r0, r1))
         _lib.check(self.L.ssd_weight_transpose_batched(ops._ptr(self._tr_desc[r0:]), r1 - r0, self._tr_tiles,
                                                        ops._stream()))
+        if self.chain_pk_fwd:                                # ... and the chain's fragment-packed copies of the same tensors
+            items = []
+            for i in self.chain_pk_fwd:
+                wt = self.conv_params[i][0]
+                if tensors is None or tensors[0] <= wt.index < tensors[1]:
+                    items += [(self.view(wt, self.param_bf16), self.chain_pk_fwd[i]), (self.w_t[i], self.chain_pk_bwd[i])]
+            if items:
+                ops.chain_pack_weights(items)
 
     # ---------------------------------------------------------------- activations
     def _acts(self, B):
@@ -345,8 +374,53 @@ class SSDEngine:
             ops.conv2d_head_fwd(acts[ni + 1], self.view(wt, self.param_bf16), self.view(bt, self.param), c["loc"],
                                 c["conf"], self.num_priors[lvl], self.classes, self.level_off[lvl], ws=ws)
 
+        def after_node(i):
+            """Launch the head of the feature map node i produced, where it runs next to the trunk."""
+            lvl = fm_level.get(i)
+            if side is not None and lvl in self.SIDE_HEADS:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    head(lvl, self._ws_side)
+            elif tail is not None and lvl is not None:
+                # the small levels' heads (10x10 and below: a few workgroups each) on a third stream, as soon as their map
+                # exists: next to the extras' chain on the main stream and the 19x19 head on the side stream they cost
+                # nothing, behind them they were 190 us of a nearly idle GPU
+                ev = torch.cuda.Event()
+                ev.record(main)
+                with torch.cuda.stream(tail):
+                    tail.wait_event(ev)
+                    head(lvl, self._ws_tail)
+
         self.bits_valid = set()
         for i, nd in enumerate(self.nodes):
+            if i == self.chain_start and "fwd" in self.chain:
+                # nodes i .. end in one launch, one workgroup per image (ops.conv_chain)
+                want_bits = self.relu_bits is not None
+                layers = []
+                for j in range(i, len(self.nodes)):
+                    ndj = self.nodes[j]
+                    wt, bt = self.conv_params[j]
+                    rb = c["rbits"].get(j + 1) if want_bits else None
+                    layers.append(ops.chain_layer_fwd(self.view(wt, self.param_bf16), self.chain_pk_fwd[j], self.view(bt, self.param), acts[j + 1],
+                                                      ndj["stride"], ndj["pt"], ndj["pl"], relu=True, relu_bits=rb))
+                try:
+                    ops.conv_chain(acts[i], layers)
+                    nth = 0
+                    for j in range(i, len(self.nodes)):
+                        if layers[j - i]["relu_bits"] is not None:
+                            self.bits_valid.add(j + 1)
+                        lvl = fm_level.get(j)
+                        if lvl is not None and tail is not None and self.chain_heads_split and lvl not in self.SIDE_HEADS:
+                            nth += 1
+                            if nth % 2 == 0:
+                                head(lvl, self._ws)           # (the main stream has nothing else left to do)
+                                continue
+                        after_node(j)
+                    break
+                except NotImplementedError:           # SSD_ERR_UNSUPPORTED: nothing launched
+                    self.chain = set()
             if nd["kind"] == "conv":
                 wt, bt = self.conv_params[i]
                 nxt = self.nodes[i + 1] if i + 1 < len(self.nodes) else None
@@ -382,22 +456,7 @@ class SSDEngine:
             elif i == 0 or self.nodes[i - 1]["kind"] != "conv":
                 ops.maxpool2x2_fwd_argmax(acts[i], out=acts[i + 1], code=c["pool_code"][i],
                                           same=nd["hout"] * 2 != nd["hin"])
-            lvl = fm_level.get(i)
-            if side is not None and lvl in self.SIDE_HEADS:
-                ev = torch.cuda.Event()
-                ev.record(main)
-                with torch.cuda.stream(side):
-                    side.wait_event(ev)
-                    head(lvl, self._ws_side)
-            elif tail is not None and lvl is not None:
-                # the small levels' heads (10x10 and below: a few workgroups each) on a third stream, as soon as their map
-                # exists: next to the extras' chain on the main stream and the 19x19 head on the side stream they cost
-                # nothing, behind them they were 190 us of a nearly idle GPU
-                ev = torch.cuda.Event()
-                ev.record(main)
-                with torch.cuda.stream(tail):
-                    tail.wait_event(ev)
-                    head(lvl, self._ws_tail)
+            after_node(i)
         for lvl in range(len(self.fm)):
             if side is None or (lvl not in self.SIDE_HEADS and tail is None):
                 head(lvl, self._ws)
@@ -539,11 +598,20 @@ class SSDEngine:
                 ev.record(main)
                 with torch.cuda.stream(self._tail):
                     self._tail.wait_event(ev)
-                    ops.heads_bwd_data_sparse(heads, hl, ws=self._ws_hz, levels=big_lv)
-                    done = torch.cuda.Event()
-                    done.record(self._tail)
-                for lvl in big_lv:
-                    sparse_head_done[self.fm[lvl][0] + 1] = done
+                    if self.split_heads_dgrad == 2:
+                        # one call per level, the level the chain reaches first (19x19) first: its event does not wait for
+                        # the 38x38 level's 94 MB of stores
+                        for lvl in reversed(big_lv):
+                            ops.heads_bwd_data_sparse(heads, hl, ws=self._ws_hz, levels=[lvl])
+                            done = torch.cuda.Event()
+                            done.record(self._tail)
+                            sparse_head_done[self.fm[lvl][0] + 1] = done
+                    else:
+                        ops.heads_bwd_data_sparse(heads, hl, ws=self._ws_hz, levels=big_lv)
+                        done = torch.cuda.Event()
+                        done.record(self._tail)
+                        for lvl in big_lv:
+                            sparse_head_done[self.fm[lvl][0] + 1] = done
             else:
                 ops.heads_bwd_data_sparse(heads, hl, ws=self._ws_hz)
             for ni, _, _ in self.fm:
@@ -613,6 +681,30 @@ class SSDEngine:
         # trunk, last layer first
         unpooled = set()                          # pooling nodes whose backward pass ran inside the next convolution's data gradient
         first_fused = False
+        chained = set()
+        if self.chain_start is not None and "bwd" in self.chain:
+            # data gradients of nodes end .. chain_start in one launch (ops.conv_chain): the head of the backward pass's
+            # critical path -- nothing large can start before this chain reaches the 19x19 map
+            last = len(self.nodes) - 1
+            assert written[last + 1]
+            layers = []
+            for j in range(last, self.chain_start - 1, -1):
+                ndj = self.nodes[j]
+                use_bits = self.relu_bits is not None and j in self.bits_valid
+                layers.append(ops.chain_layer_dgrad(self.w_t[j], self.chain_pk_bwd[j], gacts[j], ndj["stride"], ndj["pt"], ndj["pl"], accumulate=written[j],
+                                                    mask_bits=c["rbits"][j] if use_bits else None,
+                                                    mask_src=None if use_bits else acts[j]))
+            try:
+                for j in range(last, self.chain_start - 1, -1):
+                    for done in (head_done, sparse_head_done):
+                        if j in done:
+                            main.wait_event(done.pop(j))
+                ops.conv_chain(gacts[last + 1], layers)
+                chained = set(range(self.chain_start, last + 1))
+                for j in chained:
+                    written[j] = True
+            except NotImplementedError:               # SSD_ERR_UNSUPPORTED: nothing launched
+                self.chain = self.chain - {"bwd"}
         for i in range(len(self.nodes) - 1, -1, -1):
             nd = self.nodes[i]
             g_out = gacts[i + 1]
@@ -640,9 +732,9 @@ class SSDEngine:
                     e1.record()
                     probe["events"].append((i, e0, e1))
             on_side(wgrad, [wt.index, bt.index])
-            if i == 0:
+            if i == 0 or i in chained:            # no gradient w.r.t. the image / its data gradient came out of the chain launch
                 opt_bucket(i)
-                continue                          # no gradient w.r.t. the image
+                continue
             if (i == 1 and self.fuse_first and not written[1] and self.nodes[0]["kind"] == "conv" and self.nodes[0]["cin"] == 8
                     and self.nodes[0]["cout"] == 64 and nd["cin"] == 64 and nd["cout"] == 64 and nd["k"] == 3 and nd["stride"] == 1
                     and nd["pt"] == 1 and nd["pl"] == 1 and self.nodes[0]["k"] == 3 and self.nodes[0]["stride"] == 1

@@ -469,17 +469,40 @@ def conv2d_bwd_data(dy, w_t, relu_src, x_shape, stride, pad_t, pad_l, accumulate
     return out
 
 
-def chain_layer_fwd(w, bias, out, stride, pad_t, pad_l, relu=True, relu_bits=None):
-    """One forward convolution of conv_chain: w bf16 [Cout,k,k,Cin], out bf16 [B,Ho,Wo,Cout]."""
-    return dict(w=w, bias=bias, out=out, ksize=w.shape[1], mul=stride, div=1, pad_t=pad_t, pad_l=pad_l, relu=relu,
+def chain_pack_weights(pairs):
+    """ssd_chain_pack_weights: [(w, packed)] with w bf16 [N,k,k,C] (forward filters, or weight_transpose's copy for the data
+    gradient) and packed a bf16 tensor of the same shape and element count that receives the fragment-packed copy conv_chain reads
+    (None: allocated).  Returns the packed tensors.  One launch for up to 16 tensors."""
+    L = _lib.lib()
+    out = []
+    for i0 in range(0, len(pairs), _lib.SSD_CHAIN_PACK_MAX):
+        chunk = pairs[i0:i0 + _lib.SSD_CHAIN_PACK_MAX]
+        arr = (_lib.ChainPack * len(chunk))()
+        for d, (w, packed) in zip(arr, chunk):
+            _bf(w)
+            if packed is None:
+                packed = torch.empty_like(w)
+            _bf(packed)
+            assert packed.numel() == w.numel()
+            d.src, d.dst, d.N, d.K = _ptr(w), _ptr(packed), w.shape[0], w.numel() // w.shape[0]
+            out.append(packed)
+        _lib.check(L.ssd_chain_pack_weights(arr, len(chunk), _stream()))
+    return out
+
+
+def chain_layer_fwd(w, packed, bias, out, stride, pad_t, pad_l, relu=True, relu_bits=None):
+    """One forward convolution of conv_chain: w bf16 [Cout,k,k,Cin] (shape only), packed = its chain_pack_weights copy (the
+    operand), out bf16 [B,Ho,Wo,Cout]."""
+    return dict(w=packed, bias=bias, out=out, ksize=w.shape[1], mul=stride, div=1, pad_t=pad_t, pad_l=pad_l, relu=relu,
                 relu_bits=relu_bits, Kc=w.shape[3], N=w.shape[0])
 
 
-def chain_layer_dgrad(w_t, out, stride, pad_t, pad_l, accumulate=False, mask_bits=None, mask_src=None):
-    """One data gradient of conv_chain: w_t bf16 [Cin,k,k,Cout_pad] (weight_transpose), out bf16 [B,H,W,Cin] = the gradient w.r.t.
-    the convolution's input (accumulated onto when `accumulate`), masked by the input activation's ReLU sign."""
+def chain_layer_dgrad(w_t, packed, out, stride, pad_t, pad_l, accumulate=False, mask_bits=None, mask_src=None):
+    """One data gradient of conv_chain: w_t bf16 [Cin,k,k,Cout_pad] (weight_transpose; shape only), packed = its
+    chain_pack_weights copy, out bf16 [B,H,W,Cin] = the gradient w.r.t. the convolution's input (accumulated onto when
+    `accumulate`), masked by the input activation's ReLU sign."""
     k = w_t.shape[1]
-    return dict(w=w_t, bias=None, out=out, ksize=k, mul=1, div=stride, pad_t=k - 1 - pad_t, pad_l=k - 1 - pad_l, relu=False,
+    return dict(w=packed, bias=None, out=out, ksize=k, mul=1, div=stride, pad_t=k - 1 - pad_t, pad_l=k - 1 - pad_l, relu=False,
                 accumulate=accumulate, mask_bits=mask_bits, mask_src=mask_src, Kc=w_t.shape[3], N=w_t.shape[0])
 
 

@@ -50,8 +50,9 @@ def make_net(ops, B, h0, spec, seed):
 def run_fwd_chain(ops, B, x, geo, ws, bs):
     outs = [torch.full((B, d["hout"], d["hout"], d["cout"]), 7.0, dtype=torch.bfloat16, device="cuda") for d in geo]
     bits = [torch.full((B, d["hout"], d["hout"], d["cout"] // 8), 0xAA, dtype=torch.uint8, device="cuda") for d in geo]
-    layers = [ops.chain_layer_fwd(w, b, o, d["s"], d["pt"], d["pt"], relu=True, relu_bits=rb)
-              for d, w, b, o, rb in zip(geo, ws, bs, outs, bits)]
+    packed = ops.chain_pack_weights([(w, None) for w in ws])
+    layers = [ops.chain_layer_fwd(w, pk, b, o, d["s"], d["pt"], d["pt"], relu=True, relu_bits=rb)
+              for d, w, pk, b, o, rb in zip(geo, ws, packed, bs, outs, bits)]
     ops.conv_chain(x, layers)
     torch.cuda.synchronize()
     return outs, bits
@@ -91,7 +92,7 @@ def run_dgrad_chain(ops, B, geo, ws, acts, g_last, heads, use_bits):
         go = heads[i].clone() if heads[i] is not None else torch.full((B, d["hin"], d["hin"], d["cin"]), 7.0, dtype=torch.bfloat16, device="cuda")
         gouts[i] = go
         wt = ops.weight_transpose(ws[i])
-        layers.append(ops.chain_layer_dgrad(wt, go, d["s"], d["pt"], d["pt"], accumulate=heads[i] is not None,
+        layers.append(ops.chain_layer_dgrad(wt, ops.chain_pack_weights([(wt, None)])[0], go, d["s"], d["pt"], d["pt"], accumulate=heads[i] is not None,
                                             mask_bits=bits_of(acts[i]) if use_bits else None, mask_src=None if use_bits else acts[i]))
     ops.conv_chain(g_last, layers)
     torch.cuda.synchronize()
@@ -152,14 +153,14 @@ def test_refusals(ops):
     w = torch.zeros((128, 1, 1, 256), dtype=torch.bfloat16, device="cuda")
     out = torch.zeros((B, 19, 19, 128), dtype=torch.bfloat16, device="cuda")
     with pytest.raises(NotImplementedError):                 # 361 pixels: not an LDS-resident map
-        ops.conv_chain(x, [ops.chain_layer_fwd(w, None, out, 1, 0, 0)])
+        ops.conv_chain(x, [ops.chain_layer_fwd(w, w, None, out, 1, 0, 0)])
     x = torch.zeros((B, 4, 4, 64), dtype=torch.bfloat16, device="cuda")
     w = torch.zeros((128, 1, 1, 64), dtype=torch.bfloat16, device="cuda")
     out = torch.zeros((B, 4, 4, 128), dtype=torch.bfloat16, device="cuda")
     with pytest.raises(NotImplementedError):                 # 64 input channels: not a multiple of 128
-        ops.conv_chain(x, [ops.chain_layer_fwd(w, None, out, 1, 0, 0)])
+        ops.conv_chain(x, [ops.chain_layer_fwd(w, w, None, out, 1, 0, 0)])
     x = torch.zeros((B, 4, 4, 128), dtype=torch.bfloat16, device="cuda")
     w = torch.zeros((128, 1, 1, 128), dtype=torch.bfloat16, device="cuda")
     w2 = torch.zeros((128, 1, 1, 256), dtype=torch.bfloat16, device="cuda")
     with pytest.raises(AssertionError):                      # the second layer does not read what the first one writes
-        ops.conv_chain(x, [ops.chain_layer_fwd(w, None, out, 1, 0, 0), ops.chain_layer_fwd(w2, None, out.clone(), 1, 0, 0)])
+        ops.conv_chain(x, [ops.chain_layer_fwd(w, w, None, out, 1, 0, 0), ops.chain_layer_fwd(w2, w2, None, out.clone(), 1, 0, 0)])

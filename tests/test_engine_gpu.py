@@ -275,6 +275,39 @@ def test_dense_head_backward_matches_the_sparse_path():
         assert (a - b).abs().max() <= 2.0 ** -6 * b.abs().max() + 1e-12, ni
 
 
+def test_chain_launch_matches_the_per_layer_schedule():
+    """The extras' six layers as one launch per direction (ops.conv_chain, engine.chain) against the per-layer kernels: the
+    chain sums k in one pass where the per-layer kernels use split-K partial sums, so activations may differ by one bf16
+    rounding -- predictions, and every gradient, agree to bf16 accuracy; the chain really is selected for nodes 17-22."""
+    import ssd_object_detection_amd.ops as ops
+    from ssd_object_detection_amd.engine import SSDEngine
+    B = 3
+    a = SSDEngine(classes=81, seed=9)
+    b = SSDEngine(classes=81, seed=9)
+    assert a.chain_start == 17 and a.chain == {"fwd", "bwd"}
+    b.chain = set()
+    g = torch.Generator().manual_seed(31)
+    x = ops.image_prep(torch.rand((B, 300, 300, 3), generator=g).cuda())
+    dloc = (torch.randn((B, 8732, 4), generator=g) * 1e-3).bfloat16().cuda()
+    dconf = (torch.randn((B, 8732, 81), generator=g) * 1e-3).bfloat16().cuda()
+    la, ca = a.forward(x)
+    lb, cb = b.forward(x)
+    assert a.chain == {"fwd", "bwd"}                         # not refused
+    assert rel_l2(la.float(), lb.float()) < 2e-3 and rel_l2(ca.float(), cb.float()) < 2e-3
+    assert torch.equal(a._acts(B)["acts"][17], b._acts(B)["acts"][17])     # in front of the chain: the same launch sequence
+    for i in range(17, 23):
+        ya, yb = a._acts(B)["acts"][i + 1].float(), b._acts(B)["acts"][i + 1].float()
+        assert (ya - yb).abs().max() <= 2.0 ** -6 * yb.abs().max() + 1e-12, i
+    a.backward(dloc, dconf)
+    b.backward(dloc, dconf)
+    torch.cuda.synchronize()
+    assert a.chain == {"fwd", "bwd"}
+    ga, gb = a.grad.cpu(), b.grad.cpu()
+    for t in gemm_arrays(a):
+        err = rel_l2(ga[t.offset:t.offset + t.numel], gb[t.offset:t.offset + t.numel])
+        assert err < 2e-2, (t.name, err)
+
+
 def test_train_step_at_batch_64():
     """BASELINE configs[2] itself, with assertions (the bench's loss_check asserts nothing): one full `_train_step` at batch
     64 on the shipped path (sparse head rows, fused first-layer pair, per-bucket clip + Adam inside the backward pass, three

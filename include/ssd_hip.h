@@ -287,6 +287,12 @@ size_t ssd_conv2d_bwd_weight_workspace_bytes(int B, int Ho, int Wo, int Cin, int
 int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias, int B, int H, int W, int Cin,
                           int Cout, int ldy, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, void* ws,
                           size_t ws_bytes, void* stream);
+/* The weight-gradient entry points finish with a fixed-order sum of per-split fp32 slabs (a small HBM-bound launch).  With a
+ * non-null stream set here (per calling thread; null = off, the default) that launch goes to `stream`, ordered behind the
+ * slab kernel by an event: the caller's stream is free for the next layer's kernel while the sum runs.  The caller then owns
+ * two obligations: dw / dbias are complete on `stream`, not on the call's own stream; and the workspace of a call must not be
+ * reused before that call's sum has run (alternate two workspaces, wait for the sum two calls back). */
+int ssd_set_wgrad_reduce_stream(void* stream);
 /* w bf16 [Cout][k][k][Cin] -> w_t bf16 [Cin][k][k][Cout_pad], spatially flipped (data-gradient operand) */
 int ssd_weight_transpose(const void* w, void* w_t, int Cout, int ksize, int Cin, int Cout_pad, void* stream);
 /* the same for `ntensors` weight tensors in one launch: desc = device array of int64 rows {w, w_t, Cout, ksize, Cin,

@@ -93,6 +93,7 @@ _SIGNATURES = {
     "ssd_quantize_mx_fp8": (ctypes.c_int, [VP, VP, VP, ctypes.c_longlong, VP]),
     "ssd_conv3x3_fwd_mxfp8": (ctypes.c_int, [VP] * 6 + [ctypes.c_int] * 6 + [VP]),
     "ssd_chain_pack_weights": (ctypes.c_int, [ctypes.POINTER(ChainPack), ctypes.c_int, VP]),
+    "ssd_set_wgrad_reduce_stream": (ctypes.c_int, [VP]),
     "ssd_conv_chain": (ctypes.c_int, [VP, ctypes.POINTER(ChainLayer), ctypes.c_int, ctypes.c_int, VP]),
     "ssd_add_relu_fwd": (ctypes.c_int, [VP, VP, VP, ctypes.c_longlong, VP]),
     "ssd_relu_mask_bwd": (ctypes.c_int, [VP, VP, VP, ctypes.c_int, ctypes.c_longlong, VP]),

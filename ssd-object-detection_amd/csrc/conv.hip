@@ -1750,6 +1750,10 @@ __global__ __launch_bounds__(WG) void k_conv_wgrad(const bf16_raw* __restrict__ 
 // (lds_read_tr16_scoped: defined in front of k_conv3x3_c64b)
 
 constexpr int WT_TILE = 64 * 512;                          // one [64 px][256 ch] image
+// STAGES = 2: two 64-pixel buffers, one step ahead, vmcnt(0) + barrier per step.  STAGES = 4 (round 4): four 32-pixel stages
+// (one MFMA k-sub-step each), three stages of DMA in flight behind a COUNTED vmcnt -- the step no longer waits for the DMA it
+// has just issued, and a stage's latency hides under three sub-steps of MFMAs instead of two.
+template <int STAGES>
 __global__ __launch_bounds__(512) void k_conv_wgrad_tile(const bf16_raw* __restrict__ x, const bf16_raw* __restrict__ dy,
                                                          float* __restrict__ slab_w, float* __restrict__ slab_b, ConvGeom g,
                                                          int m_per_split, int nsplit, int cout) {
@@ -1803,10 +1807,12 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_tile(const bf16_raw* __restr
         }
     }
     const bool pointwise = g.KH == 1 && g.KW == 1 && g.mul == 1 && g.pad_t == 0 && g.pad_l == 0;   // source pixel = output pixel
+    constexpr int NJ = STAGES == 4 ? 2 : 4;                      // DMA instructions per wave, operand and stage
+    constexpr int XOFF = STAGES == 4 ? WT_TILE / 2 : WT_TILE;     // the x image of a stage starts here
     auto issue_dma = [&](int mstep, int buf) {
-        char* base = smem + buf * (2 * WT_TILE);
+        char* base = smem + buf * (2 * XOFF);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int m = mstep + rowj[j];
             const bool mok = m < m_end;
             const unsigned od = (unsigned)m * (unsigned)g.N * 2u + dycol[j];
@@ -1814,7 +1820,7 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_tile(const bf16_raw* __restr
                                                      (mok && dycol[j] != OOB) ? od : OOB, 0, 0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int m = mstep + rowj[j];
             bool ok = m < m_end && xcol[j] != OOB;
             unsigned pix;
@@ -1831,7 +1837,7 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_tile(const bf16_raw* __restr
                 pix = (unsigned)((b * g.H + iy) * g.W + ix);
             }
             const unsigned ox_ = pix * (unsigned)g.C * 2u + xcol[j];
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)(base + WT_TILE + (wave + 8 * j) * 1024), 16,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)(base + XOFF + (wave + 8 * j) * 1024), 16,
                                                      ok ? ox_ : OOB, 0, 0, 0);
         }
     };
@@ -1859,15 +1865,51 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_tile(const bf16_raw* __restr
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int gl = wave_n * 4 + c;
-        bbase[c] = WT_TILE + kk0 * 512 + (((gl & 8) | ((gl & 7) ^ key)) << 5) + (li & 3) * 8;
+        bbase[c] = XOFF + kk0 * 512 + (((gl & 8) | ((gl & 7) ^ key)) << 5) + (li & 3) * 8;
     }
     auto rd = [&](int addr) { return lds_read_tr16_scoped(smem + addr, smem); };
 
-    const int nsteps = (m_end - m_begin + 63) / 64;
-    if (nsteps > 0) issue_dma(m_begin, 0);
+    const int nsteps = STAGES == 4 ? (m_end - m_begin + 31) / 32 : (m_end - m_begin + 63) / 64;
+    if constexpr (STAGES == 4) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            if (p < nsteps) issue_dma(m_begin + p * 32, p);
+    } else {
+        if (nsteps > 0) issue_dma(m_begin, 0);
+    }
     auto run = [&](auto bias_tag) {
         constexpr bool BIAS = decltype(bias_tag)::value;
         for (int st = 0; st < nsteps; ++st) {
+            if constexpr (STAGES == 4) {
+                // stage st has landed when at most the two younger stages' 2 * NJ instructions each are still in flight
+                const int younger = min(2, nsteps - 1 - st);
+                if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                    // ... for every wave; and stage st - 1's buffer is free (raw barrier:
+                asm volatile("" ::: "memory");                   //  __syncthreads() would wait for vmcnt(0) first)
+                if (st + 3 < nsteps) issue_dma(m_begin + (st + 3) * 32, (st + 3) & 3);
+                const int boff = (st & 3) * (2 * XOFF);
+                bf16x8_t fb[4], fa[8];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int half = 0; half < 2; ++half)
+                        reinterpret_cast<s16x4_t*>(&fb[c])[half] = rd(bbase[c] + boff + half * 4096);
+#pragma unroll
+                for (int a = 0; a < 8; ++a)
+#pragma unroll
+                    for (int half = 0; half < 2; ++half)
+                        reinterpret_cast<s16x4_t*>(&fa[a])[half] = rd(abase[a] + boff + half * 4096);
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[c], acc[a][c], 0, 0, 0);
+                    if constexpr (BIAS) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], ones, accb[a], 0, 0, 0);
+                }
+                continue;
+            }
             const int cur = st & 1;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -2659,7 +2701,7 @@ Knob g_knobs[] = {{"SSD_ABLATE", {KNOB_UNSET}}, {"SSD_DGRAD_S2", {KNOB_UNSET}},
                   {"SSD_CONV_PATCH_FLAT", {KNOB_UNSET}}, {"SSD_WGRAD_FIRST", {KNOB_UNSET}}, {"SSD_CONV_FIRST", {KNOB_UNSET}},
                   {"SSD_WGRAD_PATCH_XCD", {KNOB_UNSET}}, {"SSD_CONV_C64", {KNOB_UNSET}}, {"SSD_CONV_POOL_FUSE", {KNOB_UNSET}},
                   {"SSD_CONV_PATCH_ROWFLAT", {KNOB_UNSET}}, {"SSD_MATCH_FUSED", {KNOB_UNSET}}, {"SSD_CONV_P512", {KNOB_UNSET}},
-                  {"SSD_C64B_WGS", {KNOB_UNSET}}, {"SSD_CONV_PW", {KNOB_UNSET}}, {"SSD_PW_WGS", {KNOB_UNSET}}, {"SSD_PW_DYNAMIC", {KNOB_UNSET}}, {"SSD_SP_ABLATE", {KNOB_UNSET}}};
+                  {"SSD_C64B_WGS", {KNOB_UNSET}}, {"SSD_CONV_PW", {KNOB_UNSET}}, {"SSD_PW_WGS", {KNOB_UNSET}}, {"SSD_PW_DYNAMIC", {KNOB_UNSET}}, {"SSD_SP_ABLATE", {KNOB_UNSET}}, {"SSD_WGTILE_STAGES", {KNOB_UNSET}}};
 Knob* find_knob(const char* name) {
     for (Knob& k : g_knobs) if (!strcmp(k.name, name)) return &k;
     return nullptr;
@@ -2891,8 +2933,25 @@ bool geom_ok(int B, int H, int W, int C, int Ho, int Wo, int N, int K) {
 
 int ssd_knob(const char* name, int dflt) { return knob(name, dflt); }
 
+// Optional second stream for the slab reductions (ssd_set_wgrad_reduce_stream): per calling thread.  The reduction is ordered
+// behind the slab kernel by an event from a small ring (events are reused: a recorded-and-waited event can be re-recorded).
+static thread_local hipStream_t t_reduce_stream = nullptr;
+static thread_local hipEvent_t t_reduce_events[64];
+static thread_local int t_reduce_event_next = 0, t_reduce_events_made = 0;
+
 void ssd_launch_wgrad_reduce(hipStream_t s, const float* slab_w, long long sw, long long nw, float* dw, const float* slab_b,
                              long long sb, int nb, float* db, int ns) {
+    if (t_reduce_stream && t_reduce_stream != s) {
+        if (t_reduce_events_made < 64) {
+            for (; t_reduce_events_made < 64; ++t_reduce_events_made)
+                if (hipEventCreateWithFlags(&t_reduce_events[t_reduce_events_made], hipEventDisableTiming) != hipSuccess) break;
+        }
+        if (t_reduce_events_made == 64) {
+            hipEvent_t ev = t_reduce_events[t_reduce_event_next];
+            t_reduce_event_next = (t_reduce_event_next + 1) & 63;
+            if (hipEventRecord(ev, s) == hipSuccess && hipStreamWaitEvent(t_reduce_stream, ev, 0) == hipSuccess) s = t_reduce_stream;
+        }
+    }
     if (ns >= 32) {
         const unsigned nbw = (unsigned)((nw / 4 + 15) / 16), nbb = db ? (unsigned)((nb + 15) / 16) : 0u;
         hipLaunchKernelGGL(k_wgrad_reduce_wide, dim3(nbw + nbb), dim3(256), 0, s, slab_w, sw, nw, dw, slab_b, sb, nb, db, ns, nbw);
@@ -2903,6 +2962,11 @@ void ssd_launch_wgrad_reduce(hipStream_t s, const float* slab_w, long long sw, l
 }
 
 extern "C" {
+
+int ssd_set_wgrad_reduce_stream(void* stream) {
+    t_reduce_stream = (hipStream_t)stream;
+    return SSD_OK;
+}
 
 int ssd_dev_knob(const char* name, int value) {
     if (!name) return SSD_ERR_VALUE;
@@ -3264,10 +3328,17 @@ static int conv2d_bwd_weight_impl(const void* x, const void* dy, float* dw, floa
         float* slab_w = static_cast<float*>(ws);
         float* slab_b = slab_w + (size_t)ns * ldy * ktot;
         hipStream_t s = (hipStream_t)stream;
-        static OnceLds set; if (ensure_lds(set, reinterpret_cast<const void*>(k_conv_wgrad_tile), (int)(4 * WT_TILE)) != 0) return SSD_ERR_LAUNCH;
-        hipLaunchKernelGGL(k_conv_wgrad_tile, dim3(ctiles * mtiles * ns), dim3(512), 4 * WT_TILE, s,
+if (knob("SSD_WGTILE_STAGES", 4) == 4) {
+            static OnceLds set; if (ensure_lds(set, reinterpret_cast<const void*>(k_conv_wgrad_tile<4>), (int)(4 * WT_TILE)) != 0) return SSD_ERR_LAUNCH;
+            hipLaunchKernelGGL(k_conv_wgrad_tile<4>, dim3(ctiles * mtiles * ns), dim3(512), 4 * WT_TILE, s,
                            static_cast<const bf16_raw*>(x), static_cast<const bf16_raw*>(dy), slab_w, dbias ? slab_b : nullptr, g,
                            mps, ns, Cout);
+        } else {
+            static OnceLds set; if (ensure_lds(set, reinterpret_cast<const void*>(k_conv_wgrad_tile<2>), (int)(4 * WT_TILE)) != 0) return SSD_ERR_LAUNCH;
+            hipLaunchKernelGGL(k_conv_wgrad_tile<2>, dim3(ctiles * mtiles * ns), dim3(512), 4 * WT_TILE, s,
+                           static_cast<const bf16_raw*>(x), static_cast<const bf16_raw*>(dy), slab_w, dbias ? slab_b : nullptr, g,
+                           mps, ns, Cout);
+        }
         if (hipGetLastError() != hipSuccess) return SSD_ERR_LAUNCH;
         launch_wgrad_reduce(s, slab_w, (long long)ldy * ktot, (long long)Cout * ktot, dw, slab_b, (long long)ldy, Cout, dbias, ns);
         return ssd_launch_status();

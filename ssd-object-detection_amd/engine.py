@@ -118,6 +118,13 @@ class SSDEngine:
         self.tail_stream = os.environ.get("SSD_TAIL_STREAM", "1") == "1"
         self.big_heads_side = os.environ.get("SSD_BIG_HEADS_SIDE", "1") == "1"
         self.pack_side = os.environ.get("SSD_PACK_SIDE", "1") == "1"
+        # 2 = weight gradients alternate between two side streams: measured 8.99 -> 9.36 ms (three MFMA kernels share the CUs'
+        # LDS and registers badly); 1 = one side stream
+        self.side_streams = int(os.environ.get("SSD_SIDE_STREAMS", "1"))
+        # the split reductions behind the weight-gradient kernels (0.55 ms of small HBM-bound launches per step, each in front
+        # of the next layer's kernel on the side stream) on a stream of their own (ssd_set_wgrad_reduce_stream): measured
+        # 9.02 -> 9.34 ms -- beside TWO MFMA kernels the small launches starve, and the next-but-one layer waits for them: off
+        self.reduce_stream = os.environ.get("SSD_REDUCE_STREAM", "0") == "1"
         self.split_heads_dgrad = int(os.environ.get("SSD_SPLIT_HEADS_DGRAD", "2"))   # 0 one call, 1 small | large levels, 2 ... and one call per large level
         # the heads of the maps the forward chain produces (all available at once, behind one launch): every other one on the
         # main stream instead of queueing all of them on the third
@@ -512,6 +519,14 @@ class SSDEngine:
         return gates
 
     def backward(self, dloc, dconf, on_ready=None, fused_adam=None, heads=None, on_dgrad=None):
+        try:
+            return self._backward(dloc, dconf, on_ready, fused_adam, heads, on_dgrad)
+        finally:
+            if getattr(self, "_red_active", None) is not None:   # (an exception between set and reset: do not leave the
+                self.L.ssd_set_wgrad_reduce_stream(None)          #  library sending other callers' reductions to our stream)
+                self._red_active = None
+
+    def _backward(self, dloc, dconf, on_ready=None, fused_adam=None, heads=None, on_dgrad=None):
         """Gradients of all parameters into self.grad (flat fp32) from d(loss)/d(loc), d(loss)/d(conf).
         on_ready([tensor indices]) is called right after the launches that complete those tensors' gradients (on the
         stream that runs them: an event recorded there covers them).
@@ -554,12 +569,44 @@ class SSDEngine:
                 if side is not None and ((node is not None and node in defer_nodes) or (node is None and self.opt_defer_heads)):
                     ev = torch.cuda.Event()
                     ev.record(side)                    # the bucket's weight gradients are all enqueued there by now
-                    deferred.append((t0, t1, ev))
+                    ev2 = None
+                    if getattr(self, "_side2", None) is not None and self.side_streams == 2 and on_ready is None and on_dgrad is None:
+                        ev2 = torch.cuda.Event()
+                        ev2.record(self._side2)
+                    if getattr(self, "_red_active", None) is not None:
+                        ev2 = torch.cuda.Event()
+                        ev2.record(self._red_active)
+                    deferred.append((t0, t1, ev, ev2))
                     return
-                on_side(lambda ws: self.adam_range(t0, t1, lr_t, hp["beta1"], hp["beta2"], hp["eps"], hp["clip"]), [])
+                on_side(lambda ws: self.adam_range(t0, t1, lr_t, hp["beta1"], hp["beta2"], hp["eps"], hp["clip"]), [], join=True)
 
-        def on_side(fn, tensors):
-            """Run fn (a weight-gradient launch) after everything enqueued so far on the main stream."""
+        side2 = None
+        # (not with a gradient exchange attached: its bucket launch records ONE event on the stream of the bucket's last tensor,
+        #  which covers the bucket only if all of its weight gradients ran on that stream)
+        if side is not None and self.side_streams == 2 and on_ready is None and on_dgrad is None:
+            if getattr(self, "_side2", None) is None:
+                self._side2 = torch.cuda.Stream(device=self.device)
+                self._ws_side2 = ops.MatchWorkspace()
+            side2 = self._side2
+        turn = [0]
+        red, red_events = None, []
+        if side is not None and self.reduce_stream and side2 is None and on_ready is None and on_dgrad is None:
+            if getattr(self, "_red", None) is None:
+                self._red = torch.cuda.Stream(device=self.device)
+                self._ws_side_b = ops.MatchWorkspace()
+            red = self._red
+            ev0 = torch.cuda.Event()
+            ev0.record(main)
+            red.wait_event(ev0)                                # (joins the launch sequence / a graph capture here)
+            _lib.check(self.L.ssd_set_wgrad_reduce_stream(ctypes.c_void_p(red.cuda_stream)))
+        self._red_active = red
+
+        def on_side(fn, tensors, join=False):
+            """Run fn (a weight-gradient launch) after everything enqueued so far on the main stream.
+            Reduction stream: the slab sums of the calls go to `red` (the library orders each behind its slab kernel); calls
+            alternate between two slab workspaces and call k waits for the sum of call k - 2, whose workspace it reuses.
+            join: fn reads gradients (the optimizer): behind every sum enqueued so far.
+            Two side streams (SSD_SIDE_STREAMS=2): the launches alternate between them instead."""
             if side is None:
                 fn(self._ws)
                 if on_ready:
@@ -567,9 +614,32 @@ class SSDEngine:
                 return
             ev = torch.cuda.Event()
             ev.record(main)
-            with torch.cuda.stream(side):
-                side.wait_event(ev)
-                fn(self._ws_side)
+            s_, ws_ = side, self._ws_side
+            if side2 is not None and not join:
+                turn[0] ^= 1
+                if turn[0] == 0:
+                    s_, ws_ = side2, self._ws_side2
+            with torch.cuda.stream(s_):
+                s_.wait_event(ev)
+                if join and side2 is not None:
+                    e2 = torch.cuda.Event()
+                    e2.record(side2)
+                    s_.wait_event(e2)
+                if red is not None:
+                    if join:
+                        if red_events:
+                            s_.wait_event(red_events[-1])
+                    else:
+                        k = len(red_events)
+                        if k & 1:
+                            ws_ = self._ws_side_b
+                        if k >= 2:
+                            s_.wait_event(red_events[k - 2])
+                fn(ws_)
+                if red is not None and not join:
+                    e = torch.cuda.Event()
+                    e.record(red)
+                    red_events.append(e)
                 if on_ready:
                     on_ready(tensors)
 
@@ -778,11 +848,19 @@ class SSDEngine:
         assert not opt_at
         for ev in sparse_head_done.values():      # (a large level whose map no trunk node accumulated into)
             main.wait_event(ev)
-        for t0, t1, ev in deferred:
+        for t0, t1, ev, ev2 in deferred:
             main.wait_event(ev)
+            if ev2 is not None:
+                main.wait_event(ev2)
             self.adam_range(t0, t1, lr_t, hp["beta1"], hp["beta2"], hp["eps"], hp["clip"])
         if side is not None:
             main.wait_stream(side)
+            if side2 is not None:
+                main.wait_stream(side2)
+            if red is not None:
+                main.wait_stream(red)
+                _lib.check(self.L.ssd_set_wgrad_reduce_stream(None))
+                self._red_active = None
 
     # ---------------------------------------------------------------- optimizer
     def clip_scales(self, clip=0.01):

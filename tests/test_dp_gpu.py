@@ -148,7 +148,10 @@ def test_train_cli_two_ranks_equal_split_batch(tmp_path):
     moved = np.abs(ref - p0).max()
     diff = np.abs(res[0][1] - ref)
     assert moved > 1e-4
-    assert float(diff.mean()) < 2e-7 and float((diff > 2e-6).mean()) < 0.03 and diff.max() <= 0.5 * moved
+    # Adam's first steps move EVERY element by ~lr whatever its gradient's size: an element whose near-zero gradient changes sign
+    # between the two summation orders (bucketed clip + all-reduce vs accumulate) ends up to 2 lr = `moved` apart after one
+    # flipped step.  The mean and the fraction of elements that differ at all are the check; the maximum is bounded by one flip.
+    assert float(diff.mean()) < 2e-7 and float((diff > 2e-6).mean()) < 0.03 and diff.max() <= 1.0 * moved
 
 
 def _nccl_rank_main(port, q):

@@ -26,7 +26,6 @@
 
 namespace {
 
-constexpr int CH_THREADS = 512;              // 8 waves: 2 per SIMD, 256 VGPRs each
 constexpr int CH_D = 16;                     // filter fragments in flight per wave (four groups of four)
 constexpr int CH_MAX_MT = 7;                 // <= 112 output pixels per image and layer
 constexpr int CH_LDS_MAX = 160 * 1024;
@@ -50,7 +49,7 @@ struct ChainArgs {
 
 __device__ __forceinline__ bf16x8_t ld_frag(const bf16_raw* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
 
-template <int MT>
+template <int MT, int CH_THREADS>
 __device__ __forceinline__ void chain_layer(const ChainLayer& L, char* smem, int b, int zero_off) {
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, gq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -183,6 +182,9 @@ __device__ __forceinline__ void chain_layer(const ChainLayer& L, char* smem, int
     }
 }
 
+// CH_THREADS = 512: 8 waves, the whole register file of a CU (2 waves x ~240 VGPRs per SIMD) -- fastest alone; 256: 4 waves, each
+// owning twice the n-tiles: half a CU, so a workgroup can start beside other streams' workgroups (SSD_CHAIN_WAVES).
+template <int CH_THREADS>
 __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x;
@@ -214,10 +216,10 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(ChainArgs a) {
         __syncthreads();                                         // the layer's input is complete; the buffer it overwrites is free
         const ChainLayer& L = a.L[l];
         const int mt = (L.Ho * L.Wo + 15) >> 4;
-        if (mt <= 1) chain_layer<1>(L, smem, b, a.zero_off);
-        else if (mt <= 2) chain_layer<2>(L, smem, b, a.zero_off);
-        else if (mt <= 4) chain_layer<4>(L, smem, b, a.zero_off);
-        else chain_layer<CH_MAX_MT>(L, smem, b, a.zero_off);
+        if (mt <= 1) chain_layer<1, CH_THREADS>(L, smem, b, a.zero_off);
+        else if (mt <= 2) chain_layer<2, CH_THREADS>(L, smem, b, a.zero_off);
+        else if (mt <= 4) chain_layer<4, CH_THREADS>(L, smem, b, a.zero_off);
+        else chain_layer<CH_MAX_MT, CH_THREADS>(L, smem, b, a.zero_off);
     }
 }
 
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(256) void k_chain_pack(PackArgs a) {
     }
 }
 
-std::atomic<int> g_lds_set{0};
+std::atomic<int> g_lds_set{0}, g_lds_set4{0};
 
 }  // namespace
 
@@ -303,12 +305,15 @@ int ssd_conv_chain(const void* in0, const ssd_chain_layer* layers, int nlayers, 
         a.L[l].out_off = l + 1 < nlayers ? (((l + 1) & 1) ? (int)region[0] : 0) : -1;
     }
     for (int l = nlayers; l < SSD_CHAIN_MAX_LAYERS; ++l) a.L[l] = a.L[0];
-    if (lds > 65536 && !g_lds_set.load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_chain), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_MAX) != hipSuccess)
-            return SSD_ERR_LAUNCH;
-        g_lds_set.store(1, std::memory_order_release);
+    const bool four = ssd_knob("SSD_CHAIN_WAVES", 8) == 4;
+    const void* fn = four ? reinterpret_cast<const void*>(k_conv_chain<256>) : reinterpret_cast<const void*>(k_conv_chain<512>);
+    std::atomic<int>& once = four ? g_lds_set4 : g_lds_set;
+    if (lds > 65536 && !once.load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_MAX) != hipSuccess) return SSD_ERR_LAUNCH;
+        once.store(1, std::memory_order_release);
     }
-    hipLaunchKernelGGL(k_conv_chain, dim3(B), dim3(CH_THREADS), lds, (hipStream_t)stream, a);
+    if (four) hipLaunchKernelGGL(k_conv_chain<256>, dim3(B), dim3(256), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_conv_chain<512>, dim3(B), dim3(512), lds, (hipStream_t)stream, a);
     return ssd_launch_status();
 }
 

@@ -137,7 +137,7 @@ _SIGNATURES = {
                                               ctypes.c_float, VP, _HG, VP, ctypes.c_size_t, ctypes.c_int, VP]),
     "ssd_heads_bwd_data_sparse_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, _HL]),
     "ssd_heads_bwd_data_sparse": (ctypes.c_int, [_HG, _HL, ctypes.c_int, VP, ctypes.c_size_t, VP]),
-    "ssd_heads_bwd_data_sparse_levels": (ctypes.c_int, [_HG, _HL, ctypes.c_int, ctypes.c_uint, VP, ctypes.c_size_t, VP]),
+    "ssd_heads_bwd_data_sparse_levels": (ctypes.c_int, [_HG, _HL, ctypes.c_int, ctypes.c_uint, ctypes.c_int, VP, ctypes.c_size_t, VP]),
     "ssd_heads_bwd_weight_sparse_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, _HG, _HL]),
     "ssd_heads_bwd_weight_sparse": (ctypes.c_int, [_HG, _HL, ctypes.c_int, VP, ctypes.c_size_t, VP]),
     "ssd_loss_fwd_bwd": (ctypes.c_int, [VP, VP, ctypes.c_int, VP, VP, VP, ctypes.c_int, ctypes.c_int, ctypes.c_int,

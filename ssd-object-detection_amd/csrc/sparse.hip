@@ -153,6 +153,7 @@ struct CLevel {
 };
 struct CArgs {
     int levels, B;
+    int prezeroed;                           // the caller cleared the maps: pixels no row reaches are left alone
     CLevel lv[SSD_MAX_LEVELS];
 };
 
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256) void k_hz_col2im(CArgs a) {
 #pragma unroll
     for (int j = 0; j < C2I_PIX; ++j) {
         const int pixel = pixel0 + j;
-        if (pixel < npix && !any[j])
+        if (pixel < npix && !any[j] && !a.prezeroed)
             *reinterpret_cast<uint4*>(lv.dx + (long long)pixel * lv.Cin + cg * 8) = make_uint4(0u, 0u, 0u, 0u);
     }
 #pragma unroll
@@ -533,8 +534,8 @@ size_t ssd_heads_bwd_data_sparse_workspace_bytes(int B, const ssd_head_layers* h
     return tot;
 }
 
-int ssd_heads_bwd_data_sparse_levels(const ssd_head_grads* hg, const ssd_head_layers* hl, int B, unsigned level_mask, void* ws,
-                                     size_t ws_bytes, void* stream) {
+int ssd_heads_bwd_data_sparse_levels(const ssd_head_grads* hg, const ssd_head_layers* hl, int B, unsigned level_mask, int prezeroed,
+                                     void* ws, size_t ws_bytes, void* stream) {
     const int rc = check_heads(hg, hl, B);
     if (rc != SSD_OK) return rc;
     if (!ws || ws_bytes < ssd_heads_bwd_data_sparse_workspace_bytes(B, hl)) return SSD_ERR_WORKSPACE;
@@ -547,6 +548,7 @@ int ssd_heads_bwd_data_sparse_levels(const ssd_head_grads* hg, const ssd_head_la
     za.mask = level_mask;
     za.count = hg->count;
     ca.B = B;
+    ca.prezeroed = prezeroed ? 1 : 0;
     char* p = static_cast<char*>(ws);
     int blk = 0, cap_tiles = 0;
     for (int l = 0; l < SSD_MAX_LEVELS; ++l) {
@@ -574,7 +576,7 @@ int ssd_heads_bwd_data_sparse_levels(const ssd_head_grads* hg, const ssd_head_la
 
 int ssd_heads_bwd_data_sparse(const ssd_head_grads* hg, const ssd_head_layers* hl, int B, void* ws, size_t ws_bytes,
                               void* stream) {
-    return ssd_heads_bwd_data_sparse_levels(hg, hl, B, ~0u, ws, ws_bytes, stream);
+    return ssd_heads_bwd_data_sparse_levels(hg, hl, B, ~0u, 0, ws, ws_bytes, stream);
 }
 
 size_t ssd_heads_bwd_weight_sparse_workspace_bytes(int B, const ssd_head_grads* hg, const ssd_head_layers* hl) {

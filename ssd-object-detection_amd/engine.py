@@ -125,10 +125,17 @@ class SSDEngine:
         # of the next layer's kernel on the side stream) on a stream of their own (ssd_set_wgrad_reduce_stream): measured
         # 9.02 -> 9.34 ms -- beside TWO MFMA kernels the small launches starve, and the next-but-one layer waits for them: off
         self.reduce_stream = os.environ.get("SSD_REDUCE_STREAM", "0") == "1"
+        self.wgrad_group = int(os.environ.get("SSD_WGRAD_GROUP", "3"))
+        self.wgrad_on_main = set(int(v) for v in os.environ.get("SSD_WGRAD_ON_MAIN", "").split(",") if v.strip())   # trunk nodes      # weight-gradient launches per cross-stream wait
         self.split_heads_dgrad = int(os.environ.get("SSD_SPLIT_HEADS_DGRAD", "2"))   # 0 one call, 1 small | large levels, 2 ... and one call per large level
         # the heads of the maps the forward chain produces (all available at once, behind one launch): every other one on the
         # main stream instead of queueing all of them on the third
         self.chain_heads_split = os.environ.get("SSD_CHAIN_HEADS_SPLIT", "1") == "1"
+        # the large levels' gradient maps (38x38, 19x19: 140 MB at batch 64) are cleared during the FORWARD pass, on the third
+        # stream under a compute-bound layer, and the heads' data gradient then writes only the ~5 % of pixels a gradient row
+        # reaches: the 140 MB of zero stores leave the window behind the loss, where nothing large can run yet
+        self.prezero_maps = os.environ.get("SSD_PREZERO_MAPS", "0") == "1"   # measured neutral (9.046 vs 9.060 ms): off
+        self._prezeroed = set()
         # fused-optimizer buckets that run at the END of the main stream instead of in the side stream's queue: the side stream (weight
         # gradients) is the longer chain, the main stream finishes ~0.5 ms earlier (round 4, same-box A/B: 1 -> 4 buckets -0.06 ms)
         self.opt_defer = int(os.environ.get("SSD_OPT_DEFER", "4"))
@@ -401,7 +408,19 @@ class SSDEngine:
                     head(lvl, self._ws_tail)
 
         self.bits_valid = set()
+        self._prezeroed = set()
+        big_maps = [ni + 1 for lvl, (ni, h, ch) in enumerate(self.fm) if B * h * h >= 16384]
+        clear_at = min(9, len(self.nodes) - 1)            # under block 4 (compute-bound 3x3 layers on 38x38 maps)
         for i, nd in enumerate(self.nodes):
+            if (i == clear_at and tail is not None and self.prezero_maps and self.sparse_heads and self.split_heads_dgrad
+                    and big_maps and len(big_maps) < len(self.fm)):
+                ev = torch.cuda.Event()
+                ev.record(main)
+                with torch.cuda.stream(tail):
+                    tail.wait_event(ev)
+                    for a in big_maps:
+                        c["gacts"][a].zero_()
+                self._prezeroed = set(big_maps)
             if i == self.chain_start and "fwd" in self.chain:
                 # nodes i .. end in one launch, one workgroup per image (ops.conv_chain)
                 want_bits = self.relu_bits is not None
@@ -567,6 +586,7 @@ class SSDEngine:
             if node in opt_at:
                 t0, t1 = opt_at.pop(node)
                 if side is not None and ((node is not None and node in defer_nodes) or (node is None and self.opt_defer_heads)):
+                    flush_side()
                     ev = torch.cuda.Event()
                     ev.record(side)                    # the bucket's weight gradients are all enqueued there by now
                     ev2 = None
@@ -601,7 +621,7 @@ class SSDEngine:
             _lib.check(self.L.ssd_set_wgrad_reduce_stream(ctypes.c_void_p(red.cuda_stream)))
         self._red_active = red
 
-        def on_side(fn, tensors, join=False):
+        def on_side(fn, tensors, join=False, now=False):
             """Run fn (a weight-gradient launch) after everything enqueued so far on the main stream.
             Reduction stream: the slab sums of the calls go to `red` (the library orders each behind its slab kernel); calls
             alternate between two slab workspaces and call k waits for the sum of call k - 2, whose workspace it reuses.
@@ -612,15 +632,43 @@ class SSDEngine:
                 if on_ready:
                     on_ready(tensors)
                 return
+            if join or now or self.wgrad_group <= 1 or side2 is not None or red is not None:
+                flush_side()
+                run_on_side(fn, tensors, join, None)
+                return
+            # grouped: the side stream is hundreds of microseconds behind the main stream for most of the backward pass, yet every
+            # cross-stream wait costs it ~6 us of idle time (30 of them per step).  `wgrad_group` launches share ONE wait -- on the
+            # event of the LAST of them, which a stream that is behind anyway has long passed
+            pending.append((fn, tensors))
+            if len(pending) >= self.wgrad_group:
+                flush_side()
+
+        pending = []
+
+        def flush_side():
+            if not pending:
+                return
             ev = torch.cuda.Event()
             ev.record(main)
+            first = True
+            for fn_, tensors_ in pending:
+                run_on_side(fn_, tensors_, False, ev if first else False)
+                first = False
+            pending.clear()
+
+        def run_on_side(fn, tensors, join, ev):
+            """ev: None = wait for the main stream as it is now; an event = wait for it; False = no wait (grouped behind one)."""
+            if ev is None:
+                ev = torch.cuda.Event()
+                ev.record(main)
             s_, ws_ = side, self._ws_side
             if side2 is not None and not join:
                 turn[0] ^= 1
                 if turn[0] == 0:
                     s_, ws_ = side2, self._ws_side2
             with torch.cuda.stream(s_):
-                s_.wait_event(ev)
+                if ev is not False:
+                    s_.wait_event(ev)
                 if join and side2 is not None:
                     e2 = torch.cuda.Event()
                     e2.record(side2)
@@ -653,7 +701,7 @@ class SSDEngine:
             # written before the trunk chain accumulates into it), weight gradient next to it on the side stream
             hl, keep = self._head_layers(c)
             on_side(lambda ws: ops.heads_bwd_weight_sparse(heads, hl, ws=self._ws_hw),
-                    [i for wt, bt in self.head_params for t in (wt, bt) for i in t.indices])
+                    [i for wt, bt in self.head_params for t in (wt, bt) for i in t.indices], now=True)
             big_lv = [lvl for lvl, (ni, h, ch) in enumerate(self.fm) if B * h * h >= 16384]
             small_lv = [lvl for lvl in range(len(self.fm)) if lvl not in big_lv]
             if side is not None and self.split_heads_dgrad and big_lv and small_lv:
@@ -668,16 +716,18 @@ class SSDEngine:
                 ev.record(main)
                 with torch.cuda.stream(self._tail):
                     self._tail.wait_event(ev)
+                    pz = all(self.fm[lvl][0] + 1 in self._prezeroed for lvl in big_lv)
+                    self._prezeroed = set()                # (consumed: the trunk chain accumulates into the maps from here on)
                     if self.split_heads_dgrad == 2:
                         # one call per level, the level the chain reaches first (19x19) first: its event does not wait for
                         # the 38x38 level's 94 MB of stores
                         for lvl in reversed(big_lv):
-                            ops.heads_bwd_data_sparse(heads, hl, ws=self._ws_hz, levels=[lvl])
+                            ops.heads_bwd_data_sparse(heads, hl, ws=self._ws_hz, levels=[lvl], prezeroed=pz)
                             done = torch.cuda.Event()
                             done.record(self._tail)
                             sparse_head_done[self.fm[lvl][0] + 1] = done
                     else:
-                        ops.heads_bwd_data_sparse(heads, hl, ws=self._ws_hz, levels=big_lv)
+                        ops.heads_bwd_data_sparse(heads, hl, ws=self._ws_hz, levels=big_lv, prezeroed=pz)
                         done = torch.cuda.Event()
                         done.record(self._tail)
                         for lvl in big_lv:
@@ -745,7 +795,7 @@ class SSDEngine:
         for lvl in range(len(self.fm) if heads is None else 0):
             if lvl in big:
                 continue
-            on_side(lambda ws, lvl=lvl: head_wgrad(lvl, ws), [i for t in self.head_params[lvl] for i in t.indices])
+            on_side(lambda ws, lvl=lvl: head_wgrad(lvl, ws), [i for t in self.head_params[lvl] for i in t.indices], now=True)
             head_dgrad(lvl, self._ws)
         opt_bucket(None)
         # trunk, last layer first
@@ -801,7 +851,14 @@ class SSDEngine:
                 if timed:
                     e1.record()
                     probe["events"].append((i, e0, e1))
-            on_side(wgrad, [wt.index, bt.index])
+            if side is not None and i in self.wgrad_on_main:
+                # the side stream (every weight gradient + the optimizer) ends ~0.45 ms after the main stream: this layer's weight
+                # gradient runs on the MAIN stream, in front of its data gradient, and both chains end closer together
+                wgrad(self._ws)
+                if on_ready:
+                    on_ready([wt.index, bt.index])
+            else:
+                on_side(wgrad, [wt.index, bt.index])
             if i == 0 or i in chained:            # no gradient w.r.t. the image / its data gradient came out of the chain launch
                 opt_bucket(i)
                 continue
@@ -846,6 +903,7 @@ class SSDEngine:
             written[i] = True
             opt_bucket(i)
         assert not opt_at
+        flush_side()
         for ev in sparse_head_done.values():      # (a large level whose map no trunk node accumulated into)
             main.wait_event(ev)
         for t0, t1, ev, ev2 in deferred:

@@ -285,20 +285,20 @@ _heads_z_ws = MatchWorkspace()
 _heads_w_ws = MatchWorkspace()
 
 
-def heads_bwd_data_sparse(hgb, hl, ws=None, levels=None):
+def heads_bwd_data_sparse(hgb, hl, ws=None, levels=None, prezeroed=False):
     """levels: None = every level, else the levels of this call (ssd_heads_bwd_data_sparse_levels; calls with disjoint sets may
-    share `ws` on two streams)."""
+    share `ws` on two streams).  prezeroed: the caller cleared those levels' dx maps; pixels without a gradient row are skipped."""
     L = _lib.lib()
     nbytes = L.ssd_heads_bwd_data_sparse_workspace_bytes(hgb.B, ctypes.byref(hl))
     wbuf = (ws or _heads_z_ws).get(nbytes, hgb.count.device)
-    if levels is None:
+    if levels is None and not prezeroed:
         _lib.check(L.ssd_heads_bwd_data_sparse(ctypes.byref(hgb.c), ctypes.byref(hl), hgb.B, _ptr(wbuf), wbuf.numel(), _stream()))
         return
     mask = 0
-    for l in levels:
+    for l in (levels if levels is not None else range(hgb.c.levels)):
         mask |= 1 << int(l)
-    _lib.check(L.ssd_heads_bwd_data_sparse_levels(ctypes.byref(hgb.c), ctypes.byref(hl), hgb.B, mask, _ptr(wbuf), wbuf.numel(),
-                                                  _stream()))
+    _lib.check(L.ssd_heads_bwd_data_sparse_levels(ctypes.byref(hgb.c), ctypes.byref(hl), hgb.B, mask, 1 if prezeroed else 0, _ptr(wbuf),
+                                                  wbuf.numel(), _stream()))
 
 
 def heads_bwd_weight_sparse(hgb, hl, ws=None):

@@ -112,7 +112,8 @@ def head_oracle(x, w, rows_dense):
     return xr.grad.permute(0, 2, 3, 1), wr.grad.permute(0, 2, 3, 1), br.grad
 
 
-def run_heads(ops, B, conf, loc, targets, seed=0, levels=range(6), check_oracle=(0, 1, 2, 3, 4, 5), use_bits=True, split=None):
+def run_heads(ops, B, conf, loc, targets, seed=0, levels=range(6), check_oracle=(0, 1, 2, 3, 4, 5), use_bits=True, split=None,
+              prezero=False):
     cls, gloc, mask = targets
     hgb = ops.HeadGradBuffers(B, HW, NPC, NPAD)
     ops.ssd_loss_heads(conf, loc, cls, gloc, mask, hgb)
@@ -124,7 +125,7 @@ def run_heads(ops, B, conf, loc, targets, seed=0, levels=range(6), check_oracle=
         w = (0.05 * torch.randn((NPC[l] * 85, 3, 3, CIN[l]), generator=g, device="cuda")).bfloat16().contiguous()
         xs.append(x); ws.append(w)
         wts.append(ops.weight_transpose_tap(w, NPAD[l]))
-        dxs.append(torch.full_like(x, 7.0))                 # must be overwritten everywhere
+        dxs.append(torch.zeros_like(x) if (prezero and split is not None and l in split) else torch.full_like(x, 7.0))   # (7: must be overwritten everywhere)
         dws.append(torch.full(w.shape, 7.0, dtype=torch.float32, device="cuda"))
         dbs.append(torch.full((w.shape[0],), 7.0, dtype=torch.float32, device="cuda"))
         b8 = (x > 0).view(B, SIDE[l], SIDE[l], CIN[l] // 8, 8).to(torch.uint8)
@@ -138,7 +139,7 @@ def run_heads(ops, B, conf, loc, targets, seed=0, levels=range(6), check_oracle=
         other.wait_stream(torch.cuda.current_stream())
         ops.heads_bwd_data_sparse(hgb, hl, levels=[l for l in range(6) if l not in split])
         with torch.cuda.stream(other):
-            ops.heads_bwd_data_sparse(hgb, hl, levels=split)
+            ops.heads_bwd_data_sparse(hgb, hl, levels=split, prezeroed=prezero)
         torch.cuda.current_stream().wait_stream(other)
     ops.heads_bwd_weight_sparse(hgb, hl)
     torch.cuda.synchronize()
@@ -204,10 +205,11 @@ def test_level_subsets_equal_the_whole_call(ops):
     targets = make_targets(ops, B, first=40)
     conf, loc = logits(B, 25)
     whole = run_heads(ops, B, conf, loc, targets, check_oracle=())
-    for split in ([0, 1], [2, 3, 4, 5], [0, 5]):
-        parts = run_heads(ops, B, conf, loc, targets, check_oracle=(), split=split)
+    for split, prezero in (([0, 1], False), ([2, 3, 4, 5], False), ([0, 5], False), ([0, 1], True), ([1, 3], True)):
+        # prezero: the maps of `split` were cleared by the caller and the call leaves row-less pixels alone
+        parts = run_heads(ops, B, conf, loc, targets, check_oracle=(), split=split, prezero=prezero)
         for l in range(6):
-            assert torch.equal(whole[1][l].view(torch.int16), parts[1][l].view(torch.int16)), (split, l)
+            assert torch.equal(whole[1][l].view(torch.int16), parts[1][l].view(torch.int16)), (split, prezero, l)
     with pytest.raises(ValueError):
         run_heads(ops, B, conf, loc, targets, check_oracle=(), split=[0, 1, 2, 3, 4, 5])
 

@@ -287,6 +287,19 @@ size_t ssd_conv2d_bwd_weight_workspace_bytes(int B, int Ho, int Wo, int Cin, int
 int ssd_conv2d_bwd_weight(const void* x, const void* dy, float* dw, float* dbias, int B, int H, int W, int Cin,
                           int Cout, int ldy, int ksize, int stride, int pad_t, int pad_l, int Ho, int Wo, void* ws,
                           size_t ws_bytes, void* stream);
+/* Several small layers' weight gradients in two launches instead of two per layer (the extras on the 10x10 ... 1x1 maps,
+ * models/ssd_model.py:124-150): arguments per layer as ssd_conv2d_bwd_weight.  Served: layers that call would run on its
+ * generic kernel with fewer than 32 pixel splits, at most 8 per call; SSD_ERR_UNSUPPORTED otherwise, nothing launched.
+ * Bit-identical to the separate calls (same blocks, same slabs, same fixed-order sums). */
+typedef struct {
+    const void* x;
+    const void* dy;
+    float* dw;
+    float* dbias;
+    int B, H, W, Cin, Cout, ldy, ksize, stride, pad_t, pad_l, Ho, Wo;
+} ssd_wgrad_item;
+size_t ssd_conv2d_bwd_weight_batched_workspace_bytes(const ssd_wgrad_item* items, int count);
+int ssd_conv2d_bwd_weight_batched(const ssd_wgrad_item* items, int count, void* ws, size_t ws_bytes, void* stream);
 /* The weight-gradient entry points finish with a fixed-order sum of per-split fp32 slabs (a small HBM-bound launch).  With a
  * non-null stream set here (per calling thread; null = off, the default) that launch goes to `stream`, ordered behind the
  * slab kernel by an event: the caller's stream is free for the next layer's kernel while the sum runs.  The caller then owns

@@ -57,6 +57,12 @@ class ChainLayer(ctypes.Structure):
                                             "accumulate")]
 
 
+class WgradItem(ctypes.Structure):
+    """ssd_wgrad_item: one layer of ssd_conv2d_bwd_weight_batched."""
+    _fields_ = [("x", VP), ("dy", VP), ("dw", VP), ("dbias", VP)] + \
+               [(n, ctypes.c_int) for n in ("B", "H", "W", "Cin", "Cout", "ldy", "ksize", "stride", "pad_t", "pad_l", "Ho", "Wo")]
+
+
 class ChainPack(ctypes.Structure):
     """ssd_chain_pack: one filter tensor of ssd_chain_pack_weights."""
     _fields_ = [("src", VP), ("dst", VP), ("N", ctypes.c_int), ("K", ctypes.c_int)]
@@ -94,6 +100,8 @@ _SIGNATURES = {
     "ssd_conv3x3_fwd_mxfp8": (ctypes.c_int, [VP] * 6 + [ctypes.c_int] * 6 + [VP]),
     "ssd_chain_pack_weights": (ctypes.c_int, [ctypes.POINTER(ChainPack), ctypes.c_int, VP]),
     "ssd_set_wgrad_reduce_stream": (ctypes.c_int, [VP]),
+    "ssd_conv2d_bwd_weight_batched_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(WgradItem), ctypes.c_int]),
+    "ssd_conv2d_bwd_weight_batched": (ctypes.c_int, [ctypes.POINTER(WgradItem), ctypes.c_int, VP, ctypes.c_size_t, VP]),
     "ssd_conv_chain": (ctypes.c_int, [VP, ctypes.POINTER(ChainLayer), ctypes.c_int, ctypes.c_int, VP]),
     "ssd_add_relu_fwd": (ctypes.c_int, [VP, VP, VP, ctypes.c_longlong, VP]),
     "ssd_relu_mask_bwd": (ctypes.c_int, [VP, VP, VP, ctypes.c_int, ctypes.c_longlong, VP]),

@@ -125,6 +125,8 @@ class SSDEngine:
         # of the next layer's kernel on the side stream) on a stream of their own (ssd_set_wgrad_reduce_stream): measured
         # 9.02 -> 9.34 ms -- beside TWO MFMA kernels the small launches starve, and the next-but-one layer waits for them: off
         self.reduce_stream = os.environ.get("SSD_REDUCE_STREAM", "0") == "1"
+        self.batch_chain_wgrads = os.environ.get("SSD_BATCH_CHAIN_WGRADS", "1") == "1"
+        self.batch_chain_front = os.environ.get("SSD_BATCH_CHAIN_FRONT", "1") == "1"
         self.wgrad_group = int(os.environ.get("SSD_WGRAD_GROUP", "3"))
         self.wgrad_on_main = set(int(v) for v in os.environ.get("SSD_WGRAD_ON_MAIN", "").split(",") if v.strip())   # trunk nodes      # weight-gradient launches per cross-stream wait
         self.split_heads_dgrad = int(os.environ.get("SSD_SPLIT_HEADS_DGRAD", "2"))   # 0 one call, 1 small | large levels, 2 ... and one call per large level
@@ -825,6 +827,30 @@ class SSDEngine:
                     written[j] = True
             except NotImplementedError:               # SSD_ERR_UNSUPPORTED: nothing launched
                 self.chain = self.chain - {"bwd"}
+        batched_w = set()
+        if chained and side is not None and self.batch_chain_wgrads and side2 is None and red is None and self.wgrad_probe is None:
+            # ... and their weight gradients in two launches (slab kernel + slab sums) instead of twelve
+            # (the layer in FRONT of the chain too, where the small-layer kernel serves it: its output gradient is the chain's
+            #  last result, so its weight gradient is ready at the same moment)
+            extra = [self.chain_start - 1] if (self.batch_chain_front and self.nodes[self.chain_start - 1]["kind"] == "conv") else []
+            for front in (extra, []):
+                order = sorted(chained, reverse=True) + front
+                layers, tens = [], []
+                for j in order:
+                    ndj = self.nodes[j]
+                    wt, bt = self.conv_params[j]
+                    layers.append((acts[j], gacts[j + 1], ndj["cout"], ndj["k"], ndj["stride"], ndj["pt"], ndj["pl"],
+                                   self.view(wt, self.grad), self.view(bt, self.grad)))
+                    tens += [wt.index, bt.index]
+                try:
+                    on_side(lambda ws: ops.conv2d_bwd_weight_batched(layers, ws=ws), tens, now=True)
+                    batched_w = set(order)
+                    break
+                except NotImplementedError:           # SSD_ERR_UNSUPPORTED: nothing launched
+                    if front:
+                        self.batch_chain_front = False
+                    else:
+                        self.batch_chain_wgrads = False
         for i in range(len(self.nodes) - 1, -1, -1):
             nd = self.nodes[i]
             g_out = gacts[i + 1]
@@ -851,7 +877,9 @@ class SSDEngine:
                 if timed:
                     e1.record()
                     probe["events"].append((i, e0, e1))
-            if side is not None and i in self.wgrad_on_main:
+            if i in batched_w:
+                pass                                  # (its weight gradient left with the batched launch above)
+            elif side is not None and i in self.wgrad_on_main:
                 # the side stream (every weight gradient + the optimizer) ends ~0.45 ms after the main stream: this layer's weight
                 # gradient runs on the MAIN stream, in front of its data gradient, and both chains end closer together
                 wgrad(self._ws)

@@ -631,6 +631,27 @@ def conv2d_bwd_weight(x, dy, Cout, k, stride, pad_t, pad_l, dw=None, dbias=None,
     return dw, dbias
 
 
+def conv2d_bwd_weight_batched(layers, ws=None):
+    """ssd_conv2d_bwd_weight_batched: layers = [(x, dy, Cout, k, stride, pad_t, pad_l, dw, dbias)] (arguments of conv2d_bwd_weight,
+    dw / dbias given) in two launches; bit-identical to the separate calls.  NotImplementedError (SSD_ERR_UNSUPPORTED, nothing
+    launched) when a layer is not one the generic small-layer kernel serves."""
+    L = _lib.lib()
+    arr = (_lib.WgradItem * len(layers))()
+    for d, (x, dy, Cout, k, stride, pad_t, pad_l, dw, dbias) in zip(arr, layers):
+        _bf(x); _bf(dy)
+        B, H, W, Cin = x.shape
+        _, Ho, Wo, ldy = dy.shape
+        assert dw.dtype == torch.float32 and dw.shape == (Cout, k, k, Cin) and dw.is_contiguous()
+        d.x, d.dy, d.dw, d.dbias = _ptr(x), _ptr(dy), _ptr(dw), _ptr(dbias)
+        d.B, d.H, d.W, d.Cin, d.Cout, d.ldy, d.ksize, d.stride, d.pad_t, d.pad_l, d.Ho, d.Wo = B, H, W, Cin, Cout, ldy, k, stride, pad_t, pad_l, Ho, Wo
+    nbytes = L.ssd_conv2d_bwd_weight_batched_workspace_bytes(arr, len(layers))
+    wbuf = (ws or _conv_ws).get(nbytes, layers[0][0].device)
+    rc = L.ssd_conv2d_bwd_weight_batched(arr, len(layers), _ptr(wbuf), wbuf.numel(), _stream())
+    if rc == _lib.SSD_ERR_UNSUPPORTED:
+        raise NotImplementedError("ssd_conv2d_bwd_weight_batched does not serve these layers")
+    _lib.check(rc)
+
+
 def conv2d_bwd_weight_unpooled(x, dpool, pool_code, dw=None, dbias=None, want_bias=True, ws=None):
     """Weight gradient of a 3x3 / stride 1 / pad 1 convolution whose output was 2x2 max-pooled, from the gradient of the pooled
     map and the winner codes (== conv2d_bwd_weight(x, maxpool2x2_bwd_argmax(pool_code, dpool, ...)) without the un-pooled zeros:

@@ -164,3 +164,26 @@ def test_refusals(ops):
     w2 = torch.zeros((128, 1, 1, 256), dtype=torch.bfloat16, device="cuda")
     with pytest.raises(AssertionError):                      # the second layer does not read what the first one writes
         ops.conv_chain(x, [ops.chain_layer_fwd(w, w, None, out, 1, 0, 0), ops.chain_layer_fwd(w2, w2, None, out.clone(), 1, 0, 0)])
+
+
+def test_batched_weight_gradients_equal_the_separate_calls(ops):
+    """ssd_conv2d_bwd_weight_batched: the six extras' weight gradients (+ bias gradients) in two launches, bit for bit what six
+    ssd_conv2d_bwd_weight calls write; a layer of another kernel family is refused with nothing launched."""
+    B = 16
+    geo, x, ws, bs = make_net(ops, B, 10, EXTRAS, 91)
+    outs, _ = run_fwd_chain(ops, B, x, geo, ws, bs)
+    acts = [x] + outs[:-1]
+    g = torch.Generator(device="cuda").manual_seed(92)
+    dys = [(torch.randn(o.shape, generator=g, device="cuda") * 0.01).bfloat16() for o in outs]
+    sep = [ops.conv2d_bwd_weight(a, dy, d["cout"], d["k"], d["s"], d["pt"], d["pt"]) for a, dy, d in zip(acts, dys, geo)]
+    dws = [torch.full_like(w_, 7.0) for w_, _ in sep]
+    dbs = [torch.full_like(b_, 7.0) for _, b_ in sep]
+    ops.conv2d_bwd_weight_batched([(a, dy, d["cout"], d["k"], d["s"], d["pt"], d["pt"], dw, db)
+                                   for a, dy, d, dw, db in zip(acts, dys, geo, dws, dbs)])
+    torch.cuda.synchronize()
+    for (w_, b_), dw, db in zip(sep, dws, dbs):
+        assert torch.equal(w_, dw) and torch.equal(b_, db)
+    xb = torch.zeros((B, 19, 19, 1024), dtype=torch.bfloat16, device="cuda")
+    dyb = torch.zeros((B, 19, 19, 1024), dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(NotImplementedError):                 # the 256-wide tile kernel's case
+        ops.conv2d_bwd_weight_batched([(xb, dyb, 1024, 1, 1, 0, 0, torch.zeros((1024, 1, 1, 1024), device="cuda"), torch.zeros(1024, device="cuda"))])

@@ -2773,7 +2773,7 @@ Knob g_knobs[] = {{"SSD_ABLATE", {KNOB_UNSET}}, {"SSD_DGRAD_S2", {KNOB_UNSET}},
                   {"SSD_CONV_PATCH_FLAT", {KNOB_UNSET}}, {"SSD_WGRAD_FIRST", {KNOB_UNSET}}, {"SSD_CONV_FIRST", {KNOB_UNSET}},
                   {"SSD_WGRAD_PATCH_XCD", {KNOB_UNSET}}, {"SSD_CONV_C64", {KNOB_UNSET}}, {"SSD_CONV_POOL_FUSE", {KNOB_UNSET}},
                   {"SSD_CONV_PATCH_ROWFLAT", {KNOB_UNSET}}, {"SSD_MATCH_FUSED", {KNOB_UNSET}}, {"SSD_CONV_P512", {KNOB_UNSET}},
-                  {"SSD_C64B_WGS", {KNOB_UNSET}}, {"SSD_CONV_PW", {KNOB_UNSET}}, {"SSD_PW_WGS", {KNOB_UNSET}}, {"SSD_PW_DYNAMIC", {KNOB_UNSET}}, {"SSD_SP_ABLATE", {KNOB_UNSET}}, {"SSD_WGTILE_STAGES", {KNOB_UNSET}}, {"SSD_CHAIN_WAVES", {KNOB_UNSET}}};
+                  {"SSD_C64B_WGS", {KNOB_UNSET}}, {"SSD_CONV_PW", {KNOB_UNSET}}, {"SSD_PW_WGS", {KNOB_UNSET}}, {"SSD_PW_DYNAMIC", {KNOB_UNSET}}, {"SSD_SP_ABLATE", {KNOB_UNSET}}, {"SSD_WGTILE_STAGES", {KNOB_UNSET}}, {"SSD_CHAIN_WAVES", {KNOB_UNSET}}, {"SSD_WGTILE_MIN_TILES", {KNOB_UNSET}}};
 Knob* find_knob(const char* name) {
     for (Knob& k : g_knobs) if (!strcmp(k.name, name)) return &k;
     return nullptr;
@@ -3280,8 +3280,11 @@ static int wgrad_splits(long long M, int tiles) {
 
 // 256x256 GEMM weight-gradient kernel: used for wide layers the patch kernel does not serve
 static bool wgrad_use_tile(long long M, int Cout, int ldy, long long ktot, long long x_elems) {
+    // (SSD_WGTILE_MIN_TILES, development: layers with fewer 256 x 256 output tiles go to the 128 x 128 kernel -- a quarter of
+    //  the slab bytes per split at the same workgroup count)
+    const long long tiles = ((ktot + 255) / 256) * ((Cout + 255) / 256);
     return knob("SSD_WGRAD_TILE", 1) && Cout > 128 && ktot >= 256 && M >= 2048 && M * ldy < (1ll << 31) - 16 &&
-           x_elems < (1ll << 31) - 16;
+           x_elems < (1ll << 31) - 16 && tiles >= knob("SSD_WGTILE_MIN_TILES", 0);
 }
 
 // pixel splits for that kernel (one workgroup per CU): estimated time = rounds x steps per split + slab traffic

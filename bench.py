@@ -148,6 +148,9 @@ def nms_inputs(torch, B, A, dtype, seed=7, n_hot=320):
 
 
 def run_rank(args):
+    if os.environ.get("SSD_BENCH_WATCHDOG"):             # development: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["SSD_BENCH_WATCHDOG"]), exit=True)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -425,7 +428,13 @@ def kernel_sections(np, torch, ops, model, eng, pset, batches, match_out, B, res
     # the nominal dense bf16 peak and against what this device sustained for the same instruction mix in this run.
     # the same launches where they run: HIP events around them on the engine's side stream during real steps (they share the
     # CUs with the high-priority data-gradient stream there), mean over the probed steps
-    in_step = in_step_time(torch, eng, dom_nodes, step_fn)
+    # (rank 0 alone is in this function: its probe steps must not enter a collective the other ranks never join)
+    was_distributed = getattr(model, "distributed", False)
+    model.distributed = False
+    try:
+        in_step = in_step_time(torch, eng, dom_nodes, step_fn)
+    finally:
+        model.distributed = was_distributed
     dom["us_per_step_in_step"] = round(in_step * 1e6, 1)
     dom["achieved_in_step"] = round(dom["flops"] / in_step / 1e12, 2)
     dom["frac_in_step"] = round(dom["flops"] / in_step / 1e12 / PEAK_BF16_TFLOPS, 4)

@@ -364,7 +364,7 @@ class SSDEngine:
 
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("SSD_SIDE_PRIO", "0")))
             self._ws_side = ops.MatchWorkspace()
         return self._side
 

@@ -19,7 +19,6 @@ def timed(fn):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
-print("pack 12 tensors: %.1f us" % timed(lambda: ops.chain_pack_weights(list(zip(ws, pk)) + list(zip(wts, pkt)))) if False else "", end="")
 print("forward chain  B=%d: %.1f us" % (B, timed(lambda: ops.conv_chain(x, fl))))
 acts = [x] + outs[:-1]
 g_last = torch.randn(outs[-1].shape, device="cuda").bfloat16()
@@ -30,6 +29,7 @@ pkt = ops.chain_pack_weights([(w, None) for w in wts])
 dl = [ops.chain_layer_dgrad(wts[i], pkt[i], gouts[i], geo[i]["s"], geo[i]["pt"], geo[i]["pt"], accumulate=(i % 2 == 0), mask_bits=mb[i])
       for i in range(len(geo) - 1, -1, -1)]
 print("dgrad chain    B=%d: %.1f us" % (B, timed(lambda: ops.conv_chain(g_last, dl))))
+print("pack 12 tensors: %.1f us" % timed(lambda: ops.chain_pack_weights(list(zip(ws, pk)) + list(zip(wts, pkt)))))
 for i, (d, w, b, o) in enumerate(zip(geo, ws, bs, outs)):
     inp = acts[i]
     t = timed(lambda: ops.conv2d_fwd(inp, w, b, d["s"], d["pt"], d["pt"], d["hout"], d["hout"], True, out=o))

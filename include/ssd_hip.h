@@ -369,6 +369,10 @@ typedef struct {
     int N, K;
 } ssd_chain_pack;
 int ssd_chain_pack_weights(const ssd_chain_pack* items, int count, void* stream);
+/* Optional: read the packed copies (items[i].dst, N, K; src unused) into every XCD's L2 from a second stream shortly before
+ * the ssd_conv_chain launch that uses them -- the chain's workgroups stream the filters at one miss latency per 128 KB in
+ * flight when they are cold.  Reads only; no effect on results. */
+int ssd_chain_prefetch(const ssd_chain_pack* items, int count, void* stream);
 typedef struct {
     const void* w;
     const float* bias;

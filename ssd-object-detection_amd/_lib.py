@@ -99,6 +99,7 @@ _SIGNATURES = {
     "ssd_quantize_mx_fp8": (ctypes.c_int, [VP, VP, VP, ctypes.c_longlong, VP]),
     "ssd_conv3x3_fwd_mxfp8": (ctypes.c_int, [VP] * 6 + [ctypes.c_int] * 6 + [VP]),
     "ssd_chain_pack_weights": (ctypes.c_int, [ctypes.POINTER(ChainPack), ctypes.c_int, VP]),
+    "ssd_chain_prefetch": (ctypes.c_int, [ctypes.POINTER(ChainPack), ctypes.c_int, VP]),
     "ssd_set_wgrad_reduce_stream": (ctypes.c_int, [VP]),
     "ssd_conv2d_bwd_weight_batched_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(WgradItem), ctypes.c_int]),
     "ssd_conv2d_bwd_weight_batched": (ctypes.c_int, [ctypes.POINTER(WgradItem), ctypes.c_int, VP, ctypes.c_size_t, VP]),

@@ -2773,7 +2773,7 @@ Knob g_knobs[] = {{"SSD_ABLATE", {KNOB_UNSET}}, {"SSD_DGRAD_S2", {KNOB_UNSET}},
                   {"SSD_CONV_PATCH_FLAT", {KNOB_UNSET}}, {"SSD_WGRAD_FIRST", {KNOB_UNSET}}, {"SSD_CONV_FIRST", {KNOB_UNSET}},
                   {"SSD_WGRAD_PATCH_XCD", {KNOB_UNSET}}, {"SSD_CONV_C64", {KNOB_UNSET}}, {"SSD_CONV_POOL_FUSE", {KNOB_UNSET}},
                   {"SSD_CONV_PATCH_ROWFLAT", {KNOB_UNSET}}, {"SSD_MATCH_FUSED", {KNOB_UNSET}}, {"SSD_CONV_P512", {KNOB_UNSET}},
-                  {"SSD_C64B_WGS", {KNOB_UNSET}}, {"SSD_CONV_PW", {KNOB_UNSET}}, {"SSD_PW_WGS", {KNOB_UNSET}}, {"SSD_PW_DYNAMIC", {KNOB_UNSET}}, {"SSD_SP_ABLATE", {KNOB_UNSET}}, {"SSD_WGTILE_STAGES", {KNOB_UNSET}}, {"SSD_CHAIN_WAVES", {KNOB_UNSET}}, {"SSD_WGTILE_MIN_TILES", {KNOB_UNSET}}};
+                  {"SSD_C64B_WGS", {KNOB_UNSET}}, {"SSD_CONV_PW", {KNOB_UNSET}}, {"SSD_PW_WGS", {KNOB_UNSET}}, {"SSD_PW_DYNAMIC", {KNOB_UNSET}}, {"SSD_SP_ABLATE", {KNOB_UNSET}}, {"SSD_WGTILE_STAGES", {KNOB_UNSET}}, {"SSD_CHAIN_WAVES", {KNOB_UNSET}}, {"SSD_WGTILE_MIN_TILES", {KNOB_UNSET}}, {"SSD_CHAIN_TOUCH", {KNOB_UNSET}}};
 Knob* find_knob(const char* name) {
     for (Knob& k : g_knobs) if (!strcmp(k.name, name)) return &k;
     return nullptr;

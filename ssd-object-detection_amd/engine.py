@@ -133,6 +133,7 @@ class SSDEngine:
         # the heads of the maps the forward chain produces (all available at once, behind one launch): every other one on the
         # main stream instead of queueing all of them on the third
         self.chain_heads_split = os.environ.get("SSD_CHAIN_HEADS_SPLIT", "1") == "1"
+        self.chain_prefetch = os.environ.get("SSD_CHAIN_PREFETCH", "1") == "1"
         # the large levels' gradient maps (38x38, 19x19: 140 MB at batch 64) are cleared during the FORWARD pass, on the third
         # stream under a compute-bound layer, and the heads' data gradient then writes only the ~5 % of pixels a gradient row
         # reaches: the 140 MB of zero stores leave the window behind the loss, where nothing large can run yet
@@ -423,6 +424,13 @@ class SSDEngine:
                     for a in big_maps:
                         c["gacts"][a].zero_()
                 self._prezeroed = set(big_maps)
+            if (self.chain_start is not None and i == self.chain_start - 1 and "fwd" in self.chain and tail is not None
+                    and self.chain_prefetch):
+                ev = torch.cuda.Event()                   # the chain's packed filters into L2 while the layer in front of it runs
+                ev.record(main)
+                with torch.cuda.stream(tail):
+                    tail.wait_event(ev)
+                    ops.chain_prefetch([self.chain_pk_fwd[j] for j in range(self.chain_start, len(self.nodes))])
             if i == self.chain_start and "fwd" in self.chain:
                 # nodes i .. end in one launch, one workgroup per image (ops.conv_chain)
                 want_bits = self.relu_bits is not None
@@ -697,6 +705,19 @@ class SSDEngine:
         # that the main stream can walk the small levels and the extras' data-gradient chain (a dozen launches that
         # each fill a fraction of the chip) underneath them.  The accumulation order into a feature-map gradient is
         # still "head first, trunk second": the trunk launch waits for the head's event.
+        if side is not None and self.chain_start is not None and "bwd" in self.chain and self.chain_prefetch:
+            if getattr(self, "_tail", None) is None:
+                self._tail = torch.cuda.Stream(device=self.device)
+                self._ws_tail = ops.MatchWorkspace()
+            ev = torch.cuda.Event()                       # the data-gradient chain's packed filters into L2, ~50 us ahead of it
+            ev.record(main)
+            with torch.cuda.stream(self._tail):
+                self._tail.wait_event(ev)
+                ops.chain_prefetch([self.chain_pk_bwd[j] for j in range(self.chain_start, len(self.nodes))])
+            prefetch_done = torch.cuda.Event()
+            prefetch_done.record(self._tail)
+        else:
+            prefetch_done = None
         sparse_head_done = {}                              # activation index -> event after a large level's sparse data gradient
         if heads is not None:
             # all levels at once from the compact rows: data gradient on the main stream (every feature-map gradient is
@@ -932,6 +953,8 @@ class SSDEngine:
             opt_bucket(i)
         assert not opt_at
         flush_side()
+        if prefetch_done is not None:
+            main.wait_event(prefetch_done)                # (joins the third stream even where nothing else ran on it)
         for ev in sparse_head_done.values():      # (a large level whose map no trunk node accumulated into)
             main.wait_event(ev)
         for t0, t1, ev, ev2 in deferred:

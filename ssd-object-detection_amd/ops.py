@@ -490,6 +490,16 @@ def chain_pack_weights(pairs):
     return out
 
 
+def chain_prefetch(packed_list):
+    """ssd_chain_prefetch: read the packed filter copies into every XCD's L2 (call on a second stream shortly before conv_chain)."""
+    L = _lib.lib()
+    arr = (_lib.ChainPack * len(packed_list))()
+    for d, t in zip(arr, packed_list):
+        _bf(t)
+        d.src, d.dst, d.N, d.K = None, _ptr(t), t.shape[0], t.numel() // t.shape[0]
+    _lib.check(L.ssd_chain_prefetch(arr, len(packed_list), _stream()))
+
+
 def chain_layer_fwd(w, packed, bias, out, stride, pad_t, pad_l, relu=True, relu_bits=None):
     """One forward convolution of conv_chain: w bf16 [Cout,k,k,Cin] (shape only), packed = its chain_pack_weights copy (the
     operand), out bf16 [B,Ho,Wo,Cout]."""

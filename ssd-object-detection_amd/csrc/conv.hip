@@ -2773,7 +2773,7 @@ Knob g_knobs[] = {{"SSD_ABLATE", {KNOB_UNSET}}, {"SSD_DGRAD_S2", {KNOB_UNSET}},
                   {"SSD_CONV_PATCH_FLAT", {KNOB_UNSET}}, {"SSD_WGRAD_FIRST", {KNOB_UNSET}}, {"SSD_CONV_FIRST", {KNOB_UNSET}},
                   {"SSD_WGRAD_PATCH_XCD", {KNOB_UNSET}}, {"SSD_CONV_C64", {KNOB_UNSET}}, {"SSD_CONV_POOL_FUSE", {KNOB_UNSET}},
                   {"SSD_CONV_PATCH_ROWFLAT", {KNOB_UNSET}}, {"SSD_MATCH_FUSED", {KNOB_UNSET}}, {"SSD_CONV_P512", {KNOB_UNSET}},
-                  {"SSD_C64B_WGS", {KNOB_UNSET}}, {"SSD_CONV_PW", {KNOB_UNSET}}, {"SSD_PW_WGS", {KNOB_UNSET}}, {"SSD_PW_DYNAMIC", {KNOB_UNSET}}, {"SSD_SP_ABLATE", {KNOB_UNSET}}, {"SSD_WGTILE_STAGES", {KNOB_UNSET}}, {"SSD_CHAIN_WAVES", {KNOB_UNSET}}, {"SSD_WGTILE_MIN_TILES", {KNOB_UNSET}}, {"SSD_CHAIN_TOUCH", {KNOB_UNSET}}};
+                  {"SSD_C64B_WGS", {KNOB_UNSET}}, {"SSD_CONV_PW", {KNOB_UNSET}}, {"SSD_PW_WGS", {KNOB_UNSET}}, {"SSD_PW_DYNAMIC", {KNOB_UNSET}}, {"SSD_SP_ABLATE", {KNOB_UNSET}}, {"SSD_WGTILE_STAGES", {KNOB_UNSET}}, {"SSD_CHAIN_WAVES", {KNOB_UNSET}}, {"SSD_WGTILE_MIN_TILES", {KNOB_UNSET}}, {"SSD_CHAIN_TOUCH", {KNOB_UNSET}}, {"SSD_WGTILE_SLAB_X", {KNOB_UNSET}}, {"SSD_WGRAD_PATCH_WGS", {KNOB_UNSET}}};
 Knob* find_knob(const char* name) {
     for (Knob& k : g_knobs) if (!strcmp(k.name, name)) return &k;
     return nullptr;
@@ -3257,7 +3257,7 @@ static void wgrad_patch_plan(int B, int Ho, int Wo, int Cin, int Cout, int* tile
     const int ntiles = B * *tiles_x * *tiles_y;
     const int groups = (Cin / 64) * ((Cout + 63) / 64);
     const int wp_mult = knob("SSD_WGRAD_PATCH_SINGLE", 0) ? 2 : 1;
-    int want = 256 * wp_mult / groups;                       // one (two when single-buffered) workgroup per CU
+    int want = knob("SSD_WGRAD_PATCH_WGS", 256) * wp_mult / groups;   // one (two when single-buffered) workgroup per CU
     if (want < 1) want = 1;
     if (want > ntiles) want = ntiles;
     *tps = (ntiles + want - 1) / want;
@@ -3295,7 +3295,9 @@ static int wgrad_tile_splits(long long M, int tiles, long long slab_elems) {
     for (int ns = 1; ns <= 64 && ns <= maxs; ++ns) {
         const long long rounds = ((long long)tiles * ns + 255) / 256;
         const long long steps = ((M + ns - 1) / ns + 63) / 64;
-        const double cost = (double)rounds * steps * 2.2 + (double)ns * slab_elems * 8.0 / 4.0e6;   // microseconds
+        // (SSD_WGTILE_SLAB_X: weight of the slab term in tenths, development -- in the step the slab sums run beside another
+        //  stream's kernels at a third of their speed alone, and CUs this kernel leaves idle are not wasted there)
+        const double cost = (double)rounds * steps * 2.2 + (double)ns * slab_elems * 8.0 / 4.0e6 * (knob("SSD_WGTILE_SLAB_X", 10) / 10.0);   // microseconds
         if (ns == 1 || cost < best_cost) { best = ns; best_cost = cost; }
     }
     return best;

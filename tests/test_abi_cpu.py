@@ -44,6 +44,46 @@ def test_host_side_argument_checks():
     assert L.ssd_match_encode(*args, 0.5, None, None, None, None, None, 0, None) == _lib.SSD_ERR_ASSERT
 
 
+def test_round4_entries_refuse_on_the_host():
+    """ssd_conv_chain / ssd_chain_pack_weights / ssd_conv2d_bwd_weight_batched / ssd_heads_bwd_data_sparse_levels decide on the
+    host whether they serve a call -- SSD_ERR_VALUE / SSD_ERR_UNSUPPORTED come back before anything touches a device."""
+    from ssd_object_detection_amd import _lib
+    L = _lib.lib()
+    dummy = ctypes.c_void_p(0x1000)                                     # never dereferenced on these paths
+    assert L.ssd_conv_chain(None, None, 0, 1, None) == _lib.SSD_ERR_VALUE
+    lay = (_lib.ChainLayer * 2)()
+
+    def fill(d, hi, kc, ho, n, k=1):
+        d.w, d.out = dummy, dummy
+        d.Hi, d.Wi, d.Kc, d.Ho, d.Wo, d.N, d.ksize, d.mul, d.div, d.pad_t, d.pad_l = hi, hi, kc, ho, ho, n, k, 1, 1, 0, 0
+
+    fill(lay[0], 19, 256, 19, 128)                                      # 361 pixels: not an LDS-resident map
+    assert L.ssd_conv_chain(dummy, lay, 1, 4, None) == _lib.SSD_ERR_UNSUPPORTED
+    fill(lay[0], 4, 64, 4, 128)                                         # 64 input channels: not a multiple of 128
+    assert L.ssd_conv_chain(dummy, lay, 1, 4, None) == _lib.SSD_ERR_UNSUPPORTED
+    fill(lay[0], 4, 128, 4, 128)
+    fill(lay[1], 4, 256, 4, 128)                                        # does not read what layer 0 writes
+    assert L.ssd_conv_chain(dummy, lay, 2, 4, None) == _lib.SSD_ERR_VALUE
+    assert L.ssd_conv_chain(dummy, lay, _lib.SSD_CHAIN_MAX_LAYERS + 1, 4, None) == _lib.SSD_ERR_VALUE
+    packs = (_lib.ChainPack * 1)()
+    assert L.ssd_chain_pack_weights(packs, 0, None) == _lib.SSD_ERR_VALUE
+    packs[0].src, packs[0].dst, packs[0].N, packs[0].K = dummy, dummy, 24, 64          # N not a multiple of 16
+    assert L.ssd_chain_pack_weights(packs, 1, None) == _lib.SSD_ERR_VALUE
+    assert L.ssd_chain_prefetch(packs, _lib.SSD_CHAIN_PACK_MAX + 1, None) == _lib.SSD_ERR_VALUE
+    items = (_lib.WgradItem * 9)()
+    assert L.ssd_conv2d_bwd_weight_batched(None, 1, None, 0, None) == _lib.SSD_ERR_VALUE
+    assert L.ssd_conv2d_bwd_weight_batched(items, 9, dummy, 1 << 30, None) == _lib.SSD_ERR_UNSUPPORTED    # more than 8 layers
+    it = items[0]
+    it.x, it.dy, it.dw = dummy, dummy, dummy
+    it.B, it.H, it.W, it.Cin, it.Cout, it.ldy, it.ksize, it.stride, it.pad_t, it.pad_l, it.Ho, it.Wo = 64, 19, 19, 1024, 1024, 1024, 1, 1, 0, 0, 19, 19
+    assert L.ssd_conv2d_bwd_weight_batched(items, 1, None, 0, None) == _lib.SSD_ERR_WORKSPACE
+    need = L.ssd_conv2d_bwd_weight_batched_workspace_bytes(items, 1)
+    assert need > 0
+    assert L.ssd_conv2d_bwd_weight_batched(items, 1, dummy, need, None) == _lib.SSD_ERR_UNSUPPORTED       # the 256-wide tile kernel's layer
+    assert L.ssd_heads_bwd_data_sparse_levels(None, None, 4, 3, 0, None, 0, None) != _lib.SSD_OK
+    assert L.ssd_set_wgrad_reduce_stream(None) == _lib.SSD_OK
+
+
 def test_synthetic_generator_matches_fixture_inputs():
     from ssd_object_detection_amd.data_loaders.synthetic import synth_gt
     z = np.load(os.path.join(ROOT, "tests", "golden", "match_synth.npz"))

@@ -200,8 +200,15 @@ def run_rank(args):
 
     last = {}
 
+    # the whole loop body on the model's high-priority stream (what tools/train.py's loop does too): no hand-over between the
+    # caller's stream and the step's main stream per step.  SSD_BENCH_STEP_STREAM=0: the loop on the default stream.
+    step_stream = model.main_stream() if os.environ.get("SSD_BENCH_STEP_STREAM", "1") == "1" else None
+
     def step(i):
         nonlocal match_out
+        if step_stream is not None and torch.cuda.current_stream() != step_stream:
+            with torch.cuda.stream(step_stream):
+                return step(i)
         img, gt = batches[i % NBATCH]
         match_out = model.match_async(gt, out=match_out)     # A3-A5 on the device, side stream, under the forward pass
         cls, loc, mask = match_out

@@ -8,9 +8,12 @@
 // its activations fit in LDS (the largest map is 10x10x512 bf16 = 100 KB), so a workgroup walks all layers of ITS image:
 //   * the layer's input lives in LDS ([pixel][channel], rows padded by 16 bytes against bank conflicts), its output goes to
 //     LDS (the next layer's input) AND to HBM (activations: the backward pass; gradients: the weight-gradient kernels);
-//   * the filters stream from L2 / HBM straight into registers as MFMA A operands (k contiguous: [n][tap][k], which is the
-//     forward filter layout [Cout][kh][kw][Cin] and the data gradient's transposed copy [Cin][kh][kw][Cout_pad]), CH_D
-//     fragments (1 KB each) in flight per wave; every wave owns n-tiles, so a filter element is read once per workgroup;
+//   * the filters stream from L2 / HBM straight into registers as MFMA A operands, CH_D fragments (1 KB each) in flight per
+//     wave; every wave owns n-tiles, so a filter element is read once per workgroup.  They are read from a FRAGMENT-PACKED copy
+//     (k_chain_pack: [n/16][k/32][64 lanes][8], one contiguous KB per operand) of the k-contiguous filters [n][tap][k] -- the
+//     forward layout [Cout][kh][kw][Cin] / the data gradient's transposed copy [Cin][kh][kw][Cout_pad]: read in place, the 16
+//     rows of a fragment are 64-byte pieces of 16 lines and the CU's address path delivered 16 B/clk (120 / 150 us per chain
+//     instead of 50 / 79);
 //   * one code path for forward and data gradient, the implicit-GEMM kernels' geometry (conv.hip): source pixel of tap t of
 //     output o = (o * mul + t - pad) / div, taken when divisible and inside the map;
 //   * epilogues as conv_common.h's epi_store: forward bias + ReLU (+ sign bits), data gradient accumulate-then-mask.

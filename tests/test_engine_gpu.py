@@ -308,6 +308,43 @@ def test_chain_launch_matches_the_per_layer_schedule():
         assert err < 2e-2, (t.name, err)
 
 
+def test_schedule_switches_are_bitwise_neutral():
+    """Every schedule switch the engine keeps (round 4: most of them measured slower and left off) only moves the SAME launches
+    between streams, groups them or batches them into launches that run the same blocks: predictions and every gradient must
+    equal the default schedule bit for bit.  Batch 48: both large head levels (38x38, 19x19) take the split path."""
+    import ssd_object_detection_amd.ops as ops
+    from ssd_object_detection_amd.engine import SSDEngine
+    B = 48
+    eng = SSDEngine(classes=81, seed=11)
+    g = torch.Generator().manual_seed(41)
+    x = ops.image_prep(torch.rand((B, 300, 300, 3), generator=g).cuda())
+    dloc = (torch.randn((B, 8732, 4), generator=g) * 1e-3).bfloat16().cuda()
+    dconf = (torch.randn((B, 8732, 81), generator=g) * 1e-3).bfloat16().cuda()
+
+    def run():
+        eng.grad.zero_()
+        loc, conf = eng.forward(x)
+        eng.backward(dloc, dconf)
+        torch.cuda.synchronize()
+        return eng.grad.clone(), loc.clone(), conf.clone()
+
+    ref = run()
+    assert eng.chain == {"fwd", "bwd"} and eng.batch_chain_wgrads          # the default really is the chained / batched schedule
+    switches = [("wgrad_group", 1), ("batch_chain_wgrads", False), ("batch_chain_front", True), ("split_heads_dgrad", 0),
+                ("split_heads_dgrad", 1), ("prezero_maps", True), ("reduce_stream", True), ("side_streams", 2),
+                ("wgrad_on_main", {14}), ("chain_heads_split", False), ("chain_prefetch", False), ("pack_side", False)]
+    for name, value in switches:
+        saved = getattr(eng, name)
+        setattr(eng, name, value)
+        try:
+            got = run()
+        finally:
+            setattr(eng, name, saved)
+        assert torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2]), name
+        assert torch.equal(got[0], ref[0]), name
+    assert torch.equal(run()[0], ref[0])
+
+
 def test_train_step_at_batch_64():
     """BASELINE configs[2] itself, with assertions (the bench's loss_check asserts nothing): one full `_train_step` at batch
     64 on the shipped path (sparse head rows, fused first-layer pair, per-bucket clip + Adam inside the backward pass, three
